@@ -1,0 +1,413 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors G1-G6 by RUNNING THE REFERENCE.
+
+TEST INFRASTRUCTURE ONLY -- runs only in the build container (needs /root/reference).
+Outputs are small ``.npz`` fixtures committed next to this script; they are data (inputs and the
+reference's outputs), never reference source.  Version caveat recorded in every file's ``meta``:
+the reference pins scipy 1.7.3 / numpy 1.21.6, the container has scipy 1.15.3 / numpy 2.2.6.
+
+    python tests/golden/generate_golden.py          # rewrites tests/golden/g*.npz
+
+What each file pins (reference file:line):
+  g1_sim_step      test_6DOF_simulator.py:3-7  -> Simulator6DOF.step (simulator.py:69-104)
+  g2_rhs           Simulator6DOF.RHS (simulator.py:106-143) on random (y,u), incl. un-normalised q
+  g3_env_rollouts  Rocket6DOF.reset/step (rocket_env.py:180-231) with config.yaml, random actions
+  g4_ground_events same, crafted low-altitude initial conditions (terminal event simulator.py:77-90)
+  g5_reward_cases  _compute_reward/_reward_goal/_check_attitude_limits/_check_bounds_violation
+                   (rocket_env.py:317-402, :591-593) on crafted post-states
+  g6_fixed_step    reference RHS driven by textbook Euler / RK4 (the reference has no fixed-step
+                   integrator; this is the parity oracle for BASELINE configs 2-3)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _ref_loader import load_reference  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+TERMS = [
+    "atarg_tracking",
+    "thrust_penalty",
+    "eta",
+    "attitude_constraint",
+    "goal_conditions",
+    "final_position",
+    "final_velocity",
+]
+
+
+def _meta(extra=None):
+    import scipy
+
+    m = {
+        "generator": "tests/golden/generate_golden.py",
+        "reference": "Tuxliri/RL_Rocket_6DOF @ /root/reference (2024-12-20 snapshot)",
+        "numpy": np.__version__,
+        "scipy": scipy.__version__,
+        "reference_pins": "numpy==1.21.6 scipy==1.7.3 gym==0.21.0 (not installed here)",
+        "reward_terms": TERMS,
+    }
+    if extra:
+        m.update(extra)
+    return np.array(json.dumps(m))
+
+
+class _IvpSpy:
+    """Wraps scipy.solve_ivp inside the reference simulator module to record nfev / status."""
+
+    def __init__(self, sim_module):
+        self.mod = sim_module
+        self.orig = sim_module.solve_ivp
+        self.last = None
+        sim_module.solve_ivp = self
+
+    def __call__(self, *a, **k):
+        sol = self.orig(*a, **k)
+        self.last = sol
+        return sol
+
+
+def _quat_from_axis_angle(axis, ang):
+    axis = np.asarray(axis, float)
+    axis = axis / np.linalg.norm(axis)
+    return np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+
+
+def _run_episode(env, spy, actions, ic=None, max_steps=None):
+    """Drive reference env; returns list of per-step records."""
+    if ic is not None:
+        orig_sample = env.init_space.sample
+        env.init_space.sample = lambda: np.array(ic, dtype=np.float32)
+    env.reset()
+    if ic is not None:
+        env.init_space.sample = orig_sample
+    m0 = float(env.SIM.m)
+    x0 = np.array(env.SIM.state, dtype=np.float64)
+    recs = []
+    n = len(actions) if max_steps is None else min(max_steps, len(actions))
+    for k in range(n):
+        pre = np.array(env.SIM.state, dtype=np.float64)
+        a = np.asarray(actions[k], dtype=np.float32)
+        obs, rew, done, info = env.step(a)
+        rd = info["rewards_dict"]
+        recs.append(
+            dict(
+                pre=pre,
+                m0=m0,
+                action=a,
+                post=np.array(env.SIM.state, dtype=np.float64),
+                obs=np.asarray(obs, dtype=np.float32),
+                reward=float(rew),
+                terms=np.array([float(rd[t]) for t in TERMS]),
+                done=bool(done),
+                bounds=bool(info["bounds_violation"]),
+                status=int(spy.last.status),
+                nfev=int(spy.last.nfev),
+                atarg=np.array(env.get_atarg(), dtype=np.float64),
+                t=float(env.SIM.t),
+                step=k,
+            )
+        )
+        if done:
+            break
+    return x0, recs
+
+
+def _pack(recs_by_ep):
+    out = {}
+    keys = ["pre", "m0", "action", "post", "obs", "reward", "terms", "done", "bounds", "status", "nfev", "atarg", "t", "step"]
+    flat = [r for ep in recs_by_ep for r in ep]
+    for k in keys:
+        out[k] = np.array([r[k] for r in flat])
+    out["episode"] = np.array([i for i, ep in enumerate(recs_by_ep) for _ in ep], dtype=np.int32)
+    out["done"] = out["done"].astype(np.uint8)
+    out["bounds"] = out["bounds"].astype(np.uint8)
+    return out
+
+
+def main():
+    Sim, Env, cfg = load_reference()
+    sim_module = sys.modules["my_environment.utils.simulator"]
+    spy = _IvpSpy(sim_module)
+    cfg_json = json.dumps(cfg)
+
+    # ------------------------------------------------------------------ G1
+    ic = np.array([100, 100, 100, 0, 3, 4, 1, 1, 0, 0, 0, 0, 0, 50e3], dtype=np.float64)
+    s = Sim(ic.copy(), 0.5)  # default dt of Simulator6DOF (simulator.py:9)
+    out, status = s.step([0, 0, 1])
+    np.savez_compressed(
+        os.path.join(HERE, "g1_sim_step.npz"),
+        ic=ic, u=np.array([0.0, 0.0, 1.0]), dt=0.5, state=np.asarray(out, float), status=status,
+        nfev=spy.last.nfev, meta=_meta(),
+    )
+
+    # ------------------------------------------------------------------ G2
+    rng = np.random.RandomState(20240101)
+    n = 512
+    y = np.zeros((n, 14))
+    y[:, 0] = rng.uniform(-30, 2200, n)
+    y[:, 1:3] = rng.uniform(-2000, 2000, (n, 2))
+    y[:, 3:6] = rng.uniform(-300, 300, (n, 3))
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= rng.uniform(0.8, 1.2, (n, 1))  # deliberately un-normalised
+    y[:, 6:10] = q
+    y[:, 10:13] = rng.uniform(-1, 1, (n, 3))
+    y[:, 13] = rng.uniform(30e3, 42e3, n)
+    y[:8, 3:6] = 0.0  # zero-velocity rows (aero force vanishes)
+    m0 = rng.uniform(40e3, 42e3, n)
+    u = np.zeros((n, 3), dtype=np.float32)
+    u[:, 0:2] = rng.uniform(-0.35, 0.35, (n, 2))
+    u[:, 2] = rng.uniform(0, 981e3, n)
+    dy = np.zeros((n, 14))
+    for i in range(n):
+        ici = y[i].copy()
+        ici[13] = m0[i]
+        sim = Sim(ici, 0.1)
+        dy[i] = sim.RHS(0.0, y[i].copy(), u[i])  # u as float32 array, like the env passes it
+    np.savez_compressed(os.path.join(HERE, "g2_rhs.npz"), y=y, u=u, m0=m0, dy=dy, meta=_meta())
+
+    # ------------------------------------------------------------------ G3
+    env = Env(**cfg)
+    eps = []
+    x0s = []
+    for k in range(10):
+        acts = np.random.RandomState(k).uniform(-1, 1, (1000, 3)).astype(np.float32)
+        if k >= 7:  # smoother, biased actions: longer flights, different attitude history
+            acts = (0.25 * acts + np.array([0.0, 0.0, 0.15 * (k - 7)])).astype(np.float32)
+        x0, recs = _run_episode(env, spy, acts)
+        eps.append(recs)
+        x0s.append(x0)
+    g3 = _pack(eps)
+    np.savez_compressed(
+        os.path.join(HERE, "g3_env_rollouts.npz"), x0=np.array(x0s), config=np.array(cfg_json),
+        normalizer=np.asarray(env.state_normalizer, float),
+        bounds_low=np.asarray(env.position_bounds_space.low, float),
+        bounds_high=np.asarray(env.position_bounds_space.high, float),
+        meta=_meta({"dt": cfg["timestep"]}), **g3,
+    )
+
+    # ------------------------------------------------------------------ G4
+    rng = np.random.RandomState(4)
+    eps = []
+    x0s = []
+    for k in range(96):
+        icv = np.zeros(14)
+        soft = k % 3 == 0  # soft, near-pad touch-downs: exercise goal / final_velocity terms
+        icv[0] = rng.uniform(0.3, 6.0) if soft else rng.uniform(0.5, 60.0)
+        icv[1:3] = rng.uniform(-20, 20, 2) if soft else rng.uniform(-150, 150, 2)
+        icv[3] = rng.uniform(-9, -1) if soft else rng.uniform(-90, -2)
+        icv[4:6] = rng.uniform(-2, 2, 2) if soft else rng.uniform(-40, 40, 2)
+        tilt = rng.uniform(0, 0.15) if soft else rng.uniform(0, 1.4)
+        axis = np.array([0.0, *rng.normal(size=2)])
+        qq = _quat_from_axis_angle(axis + 1e-9, tilt)
+        # compose with a roll about body x
+        roll = rng.uniform(-np.pi, np.pi)
+        qr = np.array([np.cos(roll / 2), np.sin(roll / 2), 0, 0])
+        w0, v0 = qq[0], qq[1:]
+        w1, v1 = qr[0], qr[1:]
+        icv[6] = w0 * w1 - v0 @ v1
+        icv[7:10] = w0 * v1 + w1 * v0 + np.cross(v0, v1)
+        icv[10:13] = rng.uniform(-0.1, 0.1, 3) if soft else rng.uniform(-0.6, 0.6, 3)
+        icv[13] = rng.uniform(30e3, 41.5e3)
+        acts = rng.uniform(-1, 1, (400, 3)).astype(np.float32)
+        if soft:
+            acts[:, 2] = rng.uniform(-0.6, 0.1, 400)
+        x0, recs = _run_episode(env, spy, acts, ic=icv)
+        eps.append(recs)
+        x0s.append(x0)
+    g4 = _pack(eps)
+    np.savez_compressed(
+        os.path.join(HERE, "g4_ground_events.npz"), x0=np.array(x0s), config=np.array(cfg_json),
+        meta=_meta({"dt": cfg["timestep"]}), **g4,
+    )
+
+    # ------------------------------------------------------------------ G5
+    from scipy.spatial.transform import Rotation as R
+
+    rng = np.random.RandomState(5)
+    cases = []
+
+    def add_case(st, u_norm):
+        cases.append((np.asarray(st, float), np.asarray(u_norm, np.float32)))
+
+    def rand_state():
+        st = np.zeros(14)
+        st[0] = rng.uniform(-40, 2300)
+        st[1] = rng.uniform(-2300, 2300)
+        st[2] = rng.uniform(-200, 200)
+        st[3:6] = rng.uniform(-250, 250, 3)
+        qv = rng.normal(size=4)
+        st[6:10] = qv / np.linalg.norm(qv)
+        st[10:13] = rng.uniform(-1.5, 1.5, 3)
+        st[13] = rng.uniform(25e3, 42e3)
+        return st
+
+    for _ in range(600):
+        add_case(rand_state(), rng.uniform(-1, 1, 3))
+    # multi-positive-root quartics: (near) head-on approach with |r| g / |v|^2 < 1/6
+    for _ in range(200):
+        st = rand_state()
+        w = rng.uniform(30, 250)
+        sdist = rng.uniform(0.02, 0.16) * w * w / 9.81
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        d[0] = abs(d[0])
+        pert = rng.normal(size=3) * 10 ** rng.uniform(-5, -1.3)
+        vdir = -d + pert
+        vdir /= np.linalg.norm(vdir)
+        st[0:3] = d * sdist
+        st[3:6] = vdir * w
+        add_case(st, rng.uniform(-1, 1, 3))
+    # attitude just inside / outside 85 deg (pitch and yaw), and around the 10 deg landing limit
+    for ang_deg in [84.0, 84.9, 84.999, 85.001, 85.1, 86.0, 89.9, 90.0, 95.0, 9.9, 10.1, 170.0, 179.9]:
+        for ax in ([0, 1, 0], [0, 0, 1], [0, 1, 1], [1, 0, 0]):
+            for sgn in (1, -1):
+                st = rand_state()
+                st[6:10] = _quat_from_axis_angle(ax, sgn * np.deg2rad(ang_deg))
+                add_case(st, rng.uniform(-1, 1, 3))
+    # landing thresholds: |r| ~ 30 / 100, |v| ~ 10 / 50, x ~ 1e-3, |omega_i| ~ 0.2
+    for rr in [29.0, 29.99, 30.01, 31, 99.0, 99.99, 100.01, 101]:
+        for vv in [9.0, 9.99, 10.01, 11, 49.0, 49.99, 50.01, 51]:
+            for xx in [-1e-2, 0.0, 5e-16, 9e-4, 1.1e-3, 0.5]:
+                st = rand_state()
+                yz = rng.normal(size=2)
+                yz = yz / np.linalg.norm(yz) * np.sqrt(max(rr * rr - xx * xx, 0))
+                st[0] = xx
+                st[1:3] = yz
+                vd = rng.normal(size=3)
+                st[3:6] = vd / np.linalg.norm(vd) * vv
+                st[10:13] = rng.choice([0.05, 0.19, 0.21, 0.5], 3) * rng.choice([-1, 1], 3)
+                tilt = rng.choice([0.02, 0.15, 0.2, 1.0])
+                st[6:10] = _quat_from_axis_angle([0, rng.normal(), rng.normal() + 1e-9], tilt)
+                add_case(st, rng.uniform(-1, 1, 3))
+    # bounds faces (float32 compares, inclusive)
+    lo = np.asarray(env.position_bounds_space.low, float)
+    hi = np.asarray(env.position_bounds_space.high, float)
+    for ax in range(3):
+        for face in (lo, hi):
+            for eps_ in [-1.0, -1e-3, 0.0, 1e-3, 1.0]:
+                st = rand_state()
+                st[0] = rng.uniform(100, 2000)
+                st[1] = rng.uniform(-2000, 2000)
+                st[2] = rng.uniform(-150, 150)
+                st[ax] = face[ax] + eps_
+                add_case(st, rng.uniform(-1, 1, 3))
+    # mass-starved / saturation of a_targ (|a| vs T_max/m)
+    for _ in range(60):
+        st = rand_state()
+        st[0:3] = rng.uniform(1, 60, 3)
+        st[3:6] = rng.uniform(-3, 3, 3)
+        add_case(st, rng.uniform(-1, 1, 3))
+
+    env.reset()
+    n = len(cases)
+    S = np.zeros((n, 14))
+    A = np.zeros((n, 3), np.float32)
+    REW = np.zeros(n)
+    TRM = np.zeros((n, 7))
+    BND = np.zeros(n, np.uint8)
+    ATG = np.zeros((n, 3))
+    for i, (st, un) in enumerate(cases):
+        u_phys = env._denormalize_action(un)
+        # place the simulator in the crafted post-step situation (simulator.py:177-186 reads
+        # states[-1] / actions[-1]); rocket_env.py:206-215 order of operations
+        env.SIM.states.append(st.copy())
+        env.SIM.actions.append(u_phys)
+        env.SIM.state = st.copy()
+        env.state = st.copy()
+        st32 = st.astype(np.float32)
+        env.rotation_obj = R.from_quat(np.roll(st32[6:10], -1))
+        rew, rd = env._compute_reward(st32, u_phys)
+        S[i] = st
+        A[i] = un
+        REW[i] = rew
+        TRM[i] = [float(rd[t]) for t in TERMS]
+        BND[i] = env._check_bounds_violation(st32)
+        ATG[i] = env.get_atarg()
+    np.savez_compressed(
+        os.path.join(HERE, "g5_reward_cases.npz"), state=S, action=A, reward_sum=REW, terms=TRM,
+        bounds=BND, atarg=ATG, config=np.array(cfg_json), meta=_meta(),
+    )
+
+    # ------------------------------------------------------------------ G6
+    def rhs_of(sim):
+        return lambda yy, uu: np.asarray(sim.RHS(0.0, yy, uu), float)
+
+    def euler(f, y0, uu, h):
+        return y0 + h * f(y0, uu)
+
+    def rk4(f, y0, uu, h):
+        k1 = f(y0, uu)
+        k2 = f(y0 + 0.5 * h * k1, uu)
+        k3 = f(y0 + 0.5 * h * k2, uu)
+        k4 = f(y0 + h * k3, uu)
+        return y0 + h / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+    # single steps from states visited by the reference env (G3 pre-states), f32 physical actions
+    idx = np.random.RandomState(6).choice(len(g3["pre"]), 256, replace=False)
+    pre = g3["pre"][idx]
+    m0s = g3["m0"][idx]
+    an = g3["action"][idx]
+    single = {k: np.zeros((len(idx), 14)) for k in ("euler_0.04", "rk4_0.04", "rk4_0.1", "euler_0.1")}
+    for i in range(len(idx)):
+        ici = pre[i].copy()
+        ici[13] = m0s[i]
+        sim = Sim(ici, 0.1)
+        f = rhs_of(sim)
+        uu = env._denormalize_action(an[i])
+        single["euler_0.04"][i] = euler(f, pre[i], uu, 0.04)
+        single["euler_0.1"][i] = euler(f, pre[i], uu, 0.1)
+        single["rk4_0.04"][i] = rk4(f, pre[i], uu, 0.04)
+        single["rk4_0.1"][i] = rk4(f, pre[i], uu, 0.1)
+
+    # free-running rollouts (quaternion renormalised after each step like simulator.py:97;
+    # no event handling: truncated before the first x <= 0)
+    roll = {}
+    for name, stepper, h in (("euler_0.04", euler, 0.04), ("rk4_0.04", rk4, 0.04), ("rk4_0.1", rk4, 0.1)):
+        for r_i in range(2):
+            env.seed(100 + r_i)
+            env.reset()
+            y0 = np.array(env.SIM.state, float)
+            sim = Sim(y0.copy(), h)
+            f = rhs_of(sim)
+            acts = np.random.RandomState(200 + r_i).uniform(-1, 1, (1000, 3)).astype(np.float32)
+            ys = [y0]
+            for k in range(1000):
+                yn = stepper(f, ys[-1], env._denormalize_action(acts[k]), h)
+                yn[6:10] /= np.linalg.norm(yn[6:10])
+                if yn[0] <= 0 or not np.all(np.isfinite(yn)):
+                    break
+                ys.append(yn)
+            ys = np.array(ys)
+            roll[f"roll_{name}_{r_i}_states"] = ys
+            roll[f"roll_{name}_{r_i}_actions"] = acts[: len(ys) - 1]
+    np.savez_compressed(
+        os.path.join(HERE, "g6_fixed_step.npz"), pre=pre, m0=m0s, action=an,
+        **{f"single_{k}": v for k, v in single.items()}, **roll, config=np.array(cfg_json), meta=_meta(),
+    )
+
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith(".npz"):
+            print(f"{fn:28s} {os.path.getsize(os.path.join(HERE, fn)) / 1024:8.1f} KiB")
+    d = np.load(os.path.join(HERE, "g3_env_rollouts.npz"))
+    print("G3 steps", len(d["reward"]), "dones", int(d["done"].sum()), "status1", int((d["status"] == 1).sum()),
+          "bounds", int(d["bounds"].sum()), "mean nfev", d["nfev"].mean())
+    d = np.load(os.path.join(HERE, "g4_ground_events.npz"))
+    print("G4 steps", len(d["reward"]), "dones", int(d["done"].sum()), "status1", int((d["status"] == 1).sum()),
+          "goal>0", int((d["terms"][:, 4] > 0).sum()), "final_v>0", int((d["terms"][:, 6] > 0).sum()))
+    d = np.load(os.path.join(HERE, "g5_reward_cases.npz"))
+    print("G5 cases", len(d["reward_sum"]), "att", int((d["terms"][:, 3] != 0).sum()), "goal", int((d["terms"][:, 4] != 0).sum()),
+          "bounds", int(d["bounds"].sum()))
+
+
+if __name__ == "__main__":
+    main()
