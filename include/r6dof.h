@@ -1,0 +1,160 @@
+/*
+ * r6dof.h -- C ABI of the MI355X-native batched Rocket6DOF hot path (libr6dof.so).
+ *
+ * The reference (Tuxliri/RL_Rocket_6DOF) is pure Python and has no FFI seam; the seam this ABI
+ * replaces is the Python class surface itself:
+ *     my_environment/envs/rocket_env.py:201-231   Rocket6DOF.step        -> r6_step
+ *     my_environment/envs/rocket_env.py:180-199   Rocket6DOF.reset       -> r6_reset
+ *     my_environment/envs/rocket_env.py:523-524   Rocket6DOF._get_obs    -> r6_observe
+ *     my_environment/utils/simulator.py:69-104    Simulator6DOF.step     -> r6_sim_step
+ *     my_environment/utils/simulator.py:106-143   Simulator6DOF.RHS      -> r6_rhs
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every pointer in R6Buffers / the call arguments is a DEVICE pointer owned by the caller
+ *     (e.g. a torch ROCm tensor's data_ptr); the library never allocates, frees or copies.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
+ *     asynchronous, stream-ordered, stateless and re-entrant across streams and devices.
+ *   - Return value: 0 = OK, negative = -(hipError_t) or R6_E_*; r6_last_error() gives the text
+ *     (thread-local).  No C++ exception crosses the ABI.
+ *   - SoA arrays are [rows][ld] float with ld >= n (ld*4 bytes should be a multiple of 16 for
+ *     full-width accesses; torch allocations are).  AoS arrays are row-major (n, width).
+ *   - State rows (simulator.py:14-28): 0-2 position x,y,z (x = height), 3-5 velocity,
+ *     6-9 quaternion (leading scalar), 10-12 body rates, 13 mass.
+ */
+#ifndef R6DOF_H
+#define R6DOF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R6_ABI_VERSION 1
+#define R6_STATE_DIM 14
+#define R6_ACTION_DIM 3
+#define R6_NUM_TERMS 7 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
+                          goal_conditions, final_position, final_velocity (rocket_env.py:353-359) */
+
+enum { R6_EULER = 0, R6_RK4 = 1 };
+enum { R6_SHAPING_ACCELERATION = 0, R6_SHAPING_VELOCITY = 1 };
+/* bits of R6Buffers.flags[i] */
+enum { R6_FLAG_GROUND = 1, R6_FLAG_BOUNDS = 2, R6_FLAG_TRUNCATED = 4 };
+enum { R6_E_BADARG = -10001, R6_E_ALIGN = -10002 };
+/* columns of R6Buffers.stats */
+#define R6_NUM_STATS 8
+enum {
+    R6_STAT_EPISODES = 0, /* finished episodes */
+    R6_STAT_RETURN = 1,   /* sum of episode returns */
+    R6_STAT_RETURN_SQ = 2,/* sum of squared episode returns */
+    R6_STAT_LENGTH = 3,   /* sum of episode lengths */
+    R6_STAT_GROUND = 4,   /* episodes ended by the ground event */
+    R6_STAT_BOUNDS = 5,   /* episodes ended by a bounds violation */
+    R6_STAT_TRUNCATED = 6,/* episodes ended by the time limit */
+    R6_STAT_LANDED = 7    /* episodes whose last step met all landing conditions (goal term) */
+};
+#define R6_BLOCK 256      /* environments per workgroup (rows of `stats` = ceil(n / R6_BLOCK)) */
+
+/* Kernel constants: everything config.yaml's env_config can change (rocket_env.py:22-178),
+ * pre-digested on the host.  All members are 4 bytes wide (no padding anywhere). */
+typedef struct R6Params {
+    /* integrator */
+    float dt;             /* env timestep [s] (config.yaml timestep) */
+    int32_t integrator;   /* R6_EULER | R6_RK4 */
+    int32_t n_substeps;   /* >= 1 fixed sub-steps per env step */
+    int32_t shaping;      /* R6_SHAPING_* (reward_shaping_type) */
+    /* action scaling, rocket_env.py:86-87, :509-521 */
+    float max_gimbal;     /* rad */
+    float max_thrust;     /* N */
+    /* observation normaliser reciprocal, rocket_env.py:106-126, :503-504 */
+    float inv_norm[R6_STATE_DIM];
+    /* position bounds (inclusive float32 box), rocket_env.py:129-134, :591-593 */
+    float bound_lo[3];
+    float bound_hi[3];
+    /* reward coefficients, config.yaml reward_coeff */
+    float alfa, beta, eta, gamma, kappa, w_r_f, w_v_f, max_r_f, max_v_f;
+    float bounds_penalty; /* -50, rocket_env.py:228-229 */
+    /* Euler-zyx attitude limits, pre-transformed so that no inverse trig is needed:
+     *   e0 = atan2(-M01, M00), e2 = atan2(-M12, M22):  |e| > L  <=>  x < cosL * hypot(x, y)
+     *   e1 = asin(M02):                                |e| > L  <=>  |M02| > sinL
+     * cos entries are -2 when L >= pi (never exceeded / always inside), sin entries are 2 when
+     * L >= pi/2.  traj_* : trajectory_limits.attitude_limit (rocket_env.py:159, :366-369);
+     * land_* : landing_params.landing_attitude_limit (rocket_env.py:165, :386-388). */
+    float traj_c0, traj_s1, traj_c2;
+    float land_c0, land_s1, land_c2;
+    float land_radius;    /* landing_params.landing_radius, rocket_env.py:162 */
+    float land_vmax;      /* landing_params.maximum_velocity, rocket_env.py:163 */
+    float omega_lim[3];   /* hard-coded 0.2 in the reference, rocket_env.py:167 */
+    float waypoint;       /* landing_params.waypoint (velocity shaping), rocket_env.py:168 */
+    /* reset distribution U(ic_lo, ic_lo + ic_range), rocket_env.py:78-81 */
+    float ic_lo[R6_STATE_DIM];
+    float ic_range[R6_STATE_DIM];
+    /* fused wrapper epilogue (main_6DOF.py:33-53): RemoveMassFromObs, ClipReward, TimeLimit */
+    int32_t obs_dim;            /* 14 raw env, 13 = RemoveMassFromObs (wrappers.py:119-126) */
+    int32_t clip_reward;        /* 0/1 ClipReward (main_6DOF.py:33-42) */
+    float clip_lo, clip_hi;
+    int32_t max_episode_steps;  /* 0 = no TimeLimit (main_6DOF.py:31,47-50) */
+    int32_t auto_reset;         /* 0/1 re-sample done envs in-kernel (VecEnv semantics) */
+} R6Params;
+
+/* Device buffers of one shard of n environments. */
+typedef struct R6Buffers {
+    int64_t n;            /* environments in this shard */
+    int64_t ld;           /* leading dimension of every SoA array (>= n) */
+    float *state;         /* [14][ld]  in/out */
+    float *epconst;       /* [2][ld]   in/out: row 0 = m0 (initial mass -> frozen inertia,
+                                       simulator.py:42-50), row 1 = v0 = |IC velocity|
+                                       (rocket_env.py:649-651, velocity shaping only) */
+    const float *action;  /* (n,3)     in: normalised actions in [-1,1] (not clipped) */
+    float *obs;           /* (n,obs_dim) out */
+    float *reward;        /* [n]       out */
+    uint8_t *done;        /* [n]       out: exactly 0 or 1 */
+    /* ---- optional outputs / state: NULL to skip ---- */
+    uint8_t *flags;       /* [n]       out: R6_FLAG_* bits */
+    float *terms;         /* [7][ld]   out: per-term rewards (info["rewards_dict"]) */
+    float *final_obs;     /* (n,obs_dim) out: rows of done envs only ("terminal_observation") */
+    uint32_t *ep_step;    /* [n]       in/out: steps elapsed in the episode (TimeLimit/Monitor) */
+    float *ep_return;     /* [n]       in/out: running episode return (Monitor) */
+    float *fin_return;    /* [n]       out at done: episode return */
+    uint32_t *fin_length; /* [n]       out at done: episode length */
+    float *stats;         /* [ceil(n/256)][R6_NUM_STATS] in/out: per-workgroup running sums over
+                                       finished episodes (see R6_STAT_*); deterministic, no atomics */
+} R6Buffers;
+
+int r6_abi_version(void);
+size_t r6_params_size(void);   /* sizeof(R6Params), for binding self-checks */
+size_t r6_buffers_size(void);  /* sizeof(R6Buffers) */
+const char *r6_last_error(void);
+
+/* Rocket6DOF.step for n envs (rocket_env.py:201-231): denormalise action, integrate one env
+ * step (fixed Euler/RK4 sub-steps, ground-event localisation, quaternion renormalise), bounds,
+ * reward, done, observation; optional fused wrappers and in-kernel auto-reset.
+ * `seed`, `step_index` (the caller's global step counter, >= 1) and `env_offset` (global index of
+ * this shard's env 0) key the counter-based reset RNG, so results do not depend on sharding. */
+int r6_step(const R6Params *params, const R6Buffers *buf, uint64_t seed, uint64_t step_index,
+            uint64_t env_offset, void *stream);
+
+/* Rocket6DOF.reset for the envs with mask[i] != 0 (mask == NULL: all), rocket_env.py:180-199:
+ * samples the initial condition, normalises the quaternion, sets m0/v0, writes obs, zeroes the
+ * episode counters. */
+int r6_reset(const R6Params *params, const R6Buffers *buf, const uint8_t *mask, uint64_t seed,
+             uint64_t step_index, uint64_t env_offset, void *stream);
+
+/* obs <- state / normaliser (rocket_env.py:503-504, :523-524) for all n envs. */
+int r6_observe(const R6Params *params, const R6Buffers *buf, void *stream);
+
+/* Simulator6DOF.step (simulator.py:69-104) only: state in/out, physical controls
+ * u_phys (n,3) = [delta_y rad, delta_z rad, thrust N]; status[i] = 1 on ground event. */
+int r6_sim_step(const R6Params *params, float *state, const float *epconst, const float *u_phys,
+                uint8_t *status, int64_t n, int64_t ld, void *stream);
+
+/* Simulator6DOF.RHS (simulator.py:106-143): dy[14][ld] <- f(y[14][ld], u_phys (n,3)). */
+int r6_rhs(const R6Params *params, const float *y, const float *epconst, const float *u_phys,
+           float *dy, int64_t n, int64_t ld, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R6DOF_H */

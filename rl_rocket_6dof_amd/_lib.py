@@ -1,0 +1,65 @@
+"""ctypes binding of ``csrc/libr6dof.so`` (the C ABI of include/r6dof.h).
+
+There is NO CPU fallback: if the HIP library is missing or does not match the header this module
+raises, and every product entry point goes through it."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .params import R6Buffers, R6Params
+
+ABI_VERSION = 1
+_LIB = None
+
+SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_reset",
+           "r6_observe", "r6_sim_step", "r6_rhs")
+
+
+class R6Error(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libr6dof.so")
+
+
+def load():
+    """Loads (once) and returns the ctypes handle."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # torch first: its bundled libamdhip64.so (SONAME libamdhip64.so.7) must be the one HIP runtime
+    # of the process, so that torch's streams / allocations are valid in our launches.
+    import torch  # noqa: F401
+
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension is not built. Run `python -m rl_rocket_6dof_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    u64, i64, vp = C.c_uint64, C.c_int64, C.c_void_p
+    lib.r6_abi_version.restype = C.c_int
+    lib.r6_params_size.restype = C.c_size_t
+    lib.r6_buffers_size.restype = C.c_size_t
+    lib.r6_last_error.restype = C.c_char_p
+    lib.r6_step.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), u64, u64, u64, vp]
+    lib.r6_reset.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), vp, u64, u64, u64, vp]
+    lib.r6_observe.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), vp]
+    lib.r6_sim_step.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
+    lib.r6_rhs.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
+    for name in ("r6_step", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs"):
+        getattr(lib, name).restype = C.c_int
+    if lib.r6_abi_version() != ABI_VERSION:
+        raise ImportError(f"libr6dof.so ABI {lib.r6_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    if lib.r6_params_size() != C.sizeof(R6Params) or lib.r6_buffers_size() != C.sizeof(R6Buffers):
+        raise ImportError("R6Params/R6Buffers layout mismatch between params.py and libr6dof.so: rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "r6"):
+    if rc != 0:
+        msg = load().r6_last_error().decode(errors="replace")
+        raise R6Error(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,289 @@
+"""``BatchedRocket6DOF`` -- N independent Rocket6DOF environments stepped by one HIP kernel launch.
+
+Surface: stable-baselines3 ``VecEnv`` (SB3 1.6.0 public API: ``num_envs``, ``observation_space``,
+``action_space``, ``reset``, ``step_async`` / ``step_wait`` / ``step``, ``close``, ``seed``,
+``get_attr`` / ``set_attr`` / ``env_method`` / ``env_is_wrapped``), with the semantics the reference
+relies on implicitly through ``DummyVecEnv`` + ``Monitor`` + ``TimeLimit`` (main_6DOF.py:44-53):
+auto-reset on done with ``terminal_observation``, ``TimeLimit.truncated`` and ``episode`` {r,l}
+in ``infos``.  Per-env semantics are those of ``Rocket6DOF`` (reference
+my_environment/envs/rocket_env.py:180-231).
+
+All arrays live in HBM as torch tensors (state as structure-of-arrays ``[14][ld]``) and are handed
+to the kernel by pointer; ``step`` returns device tensors unless ``numpy_io=True`` (SB3 mode).
+There is no CPU path: without the HIP library / a GPU the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .compat import Box
+from .params import (ACTION_DIM, BLOCK, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS, STATE_DIM,
+                     STAT_NAMES, R6Buffers, default_env_config, make_params)
+
+TERM_NAMES_ACC = ("atarg_tracking", "thrust_penalty", "eta", "attitude_constraint", "goal_conditions",
+                  "final_position", "final_velocity")          # rocket_env.py:342-359
+TERM_NAMES_VEL = ("vtarg_tracking",) + TERM_NAMES_ACC[1:]
+
+_EXPLICIT_RESET_BASE = 1 << 60   # keeps reset() draws disjoint from in-kernel auto-reset draws
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class LazyInfos(Sequence):
+    """``infos`` of one step: behaves like SB3's list of N dicts, but dicts are built on access and
+    the device data is copied to the host once, on first access (N = 2^20 dicts per step would
+    dominate everything otherwise)."""
+
+    def __init__(self, env: "BatchedRocket6DOF"):
+        self._env = env
+        self._host = None
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def _snapshot(self):
+        if self._host is None:
+            e = self._env
+            h = {"done": e.done.cpu().numpy().astype(bool)}
+            h["flags"] = e.flags.cpu().numpy() if e.flags is not None else None
+            idx = np.nonzero(h["done"])[0]
+            h["done_idx"] = {int(k): j for j, k in enumerate(idx)}
+            if len(idx) and e.auto_reset:
+                sel = torch.as_tensor(idx, device=e.device)
+                h["final_obs"] = e.final_obs[sel].cpu().numpy()
+                h["fin_return"] = e.fin_return[sel].cpu().numpy()
+                h["fin_length"] = e.fin_length[sel].cpu().numpy()
+            h["terms"] = e.terms[:, : e.num_envs].cpu().numpy() if e.terms is not None else None
+            self._host = h
+        return self._host
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        h = self._snapshot()
+        e = self._env
+        info = {"is_done": bool(h["done"][i])}                         # rocket_env.py:219
+        if h["flags"] is not None:
+            f = int(h["flags"][i])
+            info["bounds_violation"] = bool(f & FLAG_BOUNDS)           # rocket_env.py:226
+            info["ground_contact"] = bool(f & FLAG_GROUND)
+            if e.max_episode_steps:
+                info["TimeLimit.truncated"] = bool(f & FLAG_TRUNCATED)  # gym TimeLimit
+        if h["terms"] is not None:
+            rd = {k: float(h["terms"][t, i]) for t, k in enumerate(e.term_names)}
+            info["rewards_dict"] = rd                                  # rocket_env.py:218
+            info.update(rd)                                            # rocket_env.py:223
+        if h["done"][i] and e.auto_reset:
+            j = h["done_idx"][i]
+            info["terminal_observation"] = h["final_obs"][j]           # SB3 DummyVecEnv
+            info["episode"] = {"r": float(h["fin_return"][j]), "l": int(h["fin_length"][j])}  # SB3 Monitor
+        return info
+
+
+class BatchedRocket6DOF:
+    """N Rocket6DOF environments on one MI355X; see module docstring."""
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, num_envs: int, env_config: Optional[dict] = None, *, device=None,
+                 integrator: str = "rk4", n_substeps: Optional[int] = None, timestep: Optional[float] = None,
+                 remove_mass: bool = False, clip_reward=None, max_episode_steps: int = 0,
+                 auto_reset: bool = True, seed: Optional[int] = None, env_offset: int = 0,
+                 record_terms: bool = False, record_flags: bool = True, track_episodes: bool = True,
+                 numpy_io: bool = False):
+        if num_envs < 1:
+            raise ValueError("num_envs must be >= 1")
+        self.lib = _lib.load()   # raises if the HIP extension is missing -- no fallback
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedRocket6DOF needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU implementation in this package")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (ROCm) device")
+        self.env_config = dict(env_config) if env_config is not None else default_env_config()
+        self.params, self.spec = make_params(
+            self.env_config, integrator=integrator, n_substeps=n_substeps, timestep=timestep,
+            remove_mass=remove_mass, clip_reward=clip_reward, max_episode_steps=max_episode_steps,
+            auto_reset=auto_reset)
+        self.num_envs = int(num_envs)
+        self.obs_dim = int(self.params.obs_dim)
+        self.auto_reset = bool(auto_reset)
+        self.max_episode_steps = int(max_episode_steps)
+        self.numpy_io = bool(numpy_io)
+        self.env_offset = int(env_offset)
+        self._seed = int(self.spec.seed if seed is None else seed)
+        self.term_names = TERM_NAMES_ACC if self.spec.shaping_type == "acceleration" else TERM_NAMES_VEL
+
+        self.observation_space = Box(low=-1, high=1, shape=(self.obs_dim,))   # rocket_env.py:137, wrappers.py:123
+        self.action_space = Box(low=-1, high=1, shape=(ACTION_DIM,))          # rocket_env.py:147
+        self.reward_coefficients = self.spec.reward_coefficients
+        self.state_normalizer = self.spec.state_normalizer
+        self.timestep = float(self.params.dt)
+
+        n, dev = self.num_envs, self.device
+        self.ld = ld = (n + 63) // 64 * 64
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.state = torch.zeros((STATE_DIM, ld), **f32)
+        self.epconst = torch.zeros((2, ld), **f32)
+        self._act = torch.zeros((n, ACTION_DIM), **f32)
+        self.obs = torch.zeros((n, self.obs_dim), **f32)
+        self.reward = torch.zeros((n,), **f32)
+        self.done = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        self.flags = torch.zeros((n,), dtype=torch.uint8, device=dev) if record_flags else None
+        self.terms = torch.zeros((NUM_TERMS, ld), **f32) if record_terms else None
+        self.final_obs = torch.zeros((n, self.obs_dim), **f32) if auto_reset else None
+        track = bool(track_episodes or max_episode_steps)
+        self.ep_step = torch.zeros((n,), dtype=torch.int32, device=dev) if track else None
+        self.ep_return = torch.zeros((n,), **f32) if track else None
+        self.fin_return = torch.zeros((n,), **f32) if (track and auto_reset) else None
+        self.fin_length = torch.zeros((n,), dtype=torch.int32, device=dev) if (track and auto_reset) else None
+        self.n_blocks = (n + BLOCK - 1) // BLOCK
+        self.stats = torch.zeros((self.n_blocks, NUM_STATS), **f32) if track else None
+
+        self._buf = R6Buffers()
+        self._fill_buffers(self._act)
+        self._step_count = 0     # global step counter (keys the auto-reset RNG), first step = 1
+        self._reset_count = 0
+        self._pending = None
+        self._closed = False
+
+    # ------------------------------------------------------------------------------------------
+    def _fill_buffers(self, action: torch.Tensor):
+        b = self._buf
+        b.n, b.ld = self.num_envs, self.ld
+        b.state, b.epconst = _ptr(self.state), _ptr(self.epconst)
+        b.action, b.obs, b.reward, b.done = _ptr(action), _ptr(self.obs), _ptr(self.reward), _ptr(self.done)
+        b.flags, b.terms, b.final_obs = _ptr(self.flags), _ptr(self.terms), _ptr(self.final_obs)
+        b.ep_step, b.ep_return = _ptr(self.ep_step), _ptr(self.ep_return)
+        b.fin_return, b.fin_length, b.stats = _ptr(self.fin_return), _ptr(self.fin_length), _ptr(self.stats)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _out(self, t: torch.Tensor):
+        return t.cpu().numpy() if self.numpy_io else t
+
+    # ------------------------------------------------------------------------------------------
+    def seed(self, seed: Optional[int] = None):
+        """rocket_env.py:619-621 -- reseeds the initial-condition stream."""
+        if seed is not None:
+            self._seed = int(seed)
+            self._reset_count = 0
+        return [self._seed + self.env_offset + i for i in range(min(self.num_envs, 8))]
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        """rocket_env.py:180-199 for every env (or those with mask != 0): sample the initial
+        condition from U(IC - ICRange/2, IC + ICRange/2), normalise the quaternion, new episode."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.num_envs,):
+                raise ValueError("mask must have shape (num_envs,)")
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_reset(C.byref(self.params), C.byref(self._buf), _ptr(m), self._seed,
+                                   _EXPLICIT_RESET_BASE + self._reset_count, self.env_offset, self._stream())
+        _lib.check(rc, "r6_reset")
+        self._reset_count += 1
+        if m is not None:
+            torch.cuda.current_stream(self.device).synchronize()  # keep `m` alive until consumed
+        return self._out(self.obs)
+
+    def step_async(self, actions) -> None:
+        if torch.is_tensor(actions) and actions.device == self.device and actions.dtype == torch.float32 \
+                and actions.is_contiguous() and actions.data_ptr() % 16 == 0:
+            a = actions          # zero-copy
+        else:
+            self._act.copy_(torch.as_tensor(actions, dtype=torch.float32).reshape(self.num_envs, ACTION_DIM))
+            a = self._act
+        if tuple(a.shape) != (self.num_envs, ACTION_DIM):
+            raise ValueError(f"actions must have shape ({self.num_envs}, {ACTION_DIM})")
+        self._buf.action = _ptr(a)
+        self._step_count += 1
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_step(C.byref(self.params), C.byref(self._buf), self._seed, self._step_count,
+                                  self.env_offset, self._stream())
+        _lib.check(rc, "r6_step")
+        self._pending = a   # keeps the action tensor alive until step_wait
+
+    def step_wait(self):
+        self._pending = None
+        done = self.done.view(torch.bool)
+        return self._out(self.obs), self._out(self.reward), self._out(done), LazyInfos(self)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    # ------------------------------------------------------------------------------------------
+    def get_state(self) -> torch.Tensor:
+        """(N,14) copy of the simulator states (rocket_env.py:623)."""
+        return self.state[:, : self.num_envs].t().contiguous()
+
+    def set_state(self, states, m0=None, v0=None):
+        """Loads explicit simulator states (N,14); m0 defaults to the state's mass (a fresh
+        Simulator6DOF, simulator.py:42), v0 to its speed (rocket_env.py:649-651)."""
+        s = torch.as_tensor(states, dtype=torch.float32, device=self.device).reshape(self.num_envs, STATE_DIM)
+        self.state[:, : self.num_envs] = s.t()
+        self.epconst[0, : self.num_envs] = s[:, 13] if m0 is None else torch.as_tensor(m0, dtype=torch.float32, device=self.device)
+        self.epconst[1, : self.num_envs] = s[:, 3:6].norm(dim=1) if v0 is None else torch.as_tensor(v0, dtype=torch.float32, device=self.device)
+        if self.ep_step is not None:
+            self.ep_step.zero_()
+            self.ep_return.zero_()
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_observe(C.byref(self.params), C.byref(self._buf), self._stream())
+        _lib.check(rc, "r6_observe")
+        return self._out(self.obs)
+
+    def episode_stats(self, clear: bool = True) -> dict:
+        """Sums over the episodes finished since the last clear (per-workgroup partials reduced in
+        float64 on the host)."""
+        if self.stats is None:
+            raise RuntimeError("episode tracking is disabled (track_episodes=False)")
+        s = self.stats.double().sum(0).cpu().numpy()
+        if clear:
+            self.stats.zero_()
+        return {k: float(s[i]) for i, k in enumerate(STAT_NAMES)}
+
+    # ---- SB3 VecEnv plumbing ---------------------------------------------------------------------
+    def close(self) -> None:
+        self._closed = True
+
+    def get_attr(self, attr_name: str, indices=None) -> List[Any]:
+        return [getattr(self, attr_name)] * len(self._indices(indices))
+
+    def set_attr(self, attr_name: str, value: Any, indices=None) -> None:
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name: str, *args, indices=None, **kwargs) -> List[Any]:
+        out = getattr(self, method_name)(*args, **kwargs)
+        return [out] * len(self._indices(indices))
+
+    def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
+        return [False] * len(self._indices(indices))
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+    def render(self, mode: str = "rgb_array"):
+        raise NotImplementedError("rendering (pyvista) is outside the hot path and not provided")
+
+    def __repr__(self):
+        integ = "rk4" if self.params.integrator == 1 else "euler"
+        return (f"BatchedRocket6DOF(num_envs={self.num_envs}, {integ}, dt={self.timestep}, "
+                f"substeps={self.params.n_substeps}, obs_dim={self.obs_dim}, device={self.device})")

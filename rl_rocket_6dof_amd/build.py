@@ -1,0 +1,47 @@
+"""Builds the in-tree HIP library ``csrc/libr6dof.so`` for gfx950 with hipcc (cross-compiles without
+a GPU).  ``python -m rl_rocket_6dof_amd.build`` or ``__graft_entry__.build()``."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libr6dof.so")
+SOURCES = ["r6_kernels.hip"]
+HEADERS = ["r6_device.hpp", os.path.join("..", "..", "include", "r6dof.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
+           "-fno-math-errno", "-Wall", "-Wno-unused-function",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+    if verbose:
+        print("[rl_rocket_6dof_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,469 @@
+// r6_device.hpp -- per-environment device math of the Rocket6DOF hot path (gfx950, fp32).
+//
+// One lane owns one environment; nothing here communicates across lanes.  Citations are into the
+// reference repo (my_environment/utils/simulator.py = "sim", my_environment/envs/rocket_env.py =
+// "env"); the formulas are re-derived for fp32 / CDNA4 (gimbal trig hoisted out of the RK stages,
+// mass integrated analytically, aero force applied in the inertial frame, diagonal inertia
+// expanded), not transliterated.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/r6dof.h"
+
+namespace r6 {
+
+// ---- constants hard-coded in the reference (sim:39-67) ------------------------------------------
+constexpr double kG0 = 9.81;                                   // sim:39
+constexpr double kLength = 40.0;                               // sim:43
+constexpr double kRadius = 3.66 / 2.0;                         // sim:44
+constexpr double kIsp = 360.0;                                 // sim:51
+constexpr double kCa = 0.82;                                   // sim:54-56
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kSref = kPi * kRadius * kRadius;              // sim:57
+constexpr double kRho0 = 1.225;                                // sim:58
+constexpr double kTb = 288.15;                                 // sim:59
+constexpr double kLb = -0.0065;                                // sim:60
+constexpr double kMair = 0.0289644;                            // sim:62
+constexpr double kRstar = 8.3144598;                           // sim:63
+constexpr double kArmThrust = -15.0;                           // sim:66  r_T_B = [-15,0,0]
+constexpr double kArmCp = 5.0;                                 // sim:67  r_cp_B = [5,0,0]
+constexpr double kRhoExp = 1.0 + kG0 * kMair / kRstar / kLb;   // sim:146-148  (= -4.2558)
+constexpr double kGShaping = 9.81;                             // env:548
+
+constexpr float kAeroK = (float)(0.5 * kSref * kCa);           // -> A = -kAeroK * rho * |v| * v
+constexpr float kMdotPerN = (float)(1.0 / (kG0 * kIsp));       // sim:140-141
+constexpr float kJxPerM = (float)(0.5 * kRadius * kRadius);                              // sim:46
+constexpr float kJtPerM = (float)((kLength * kLength + 3.0 * kRadius * kRadius) / 12.0); // sim:47-48
+
+// ---- fast hardware transcendentals (1 ulp class; v_rcp/v_rsq/v_sqrt/v_exp/v_log) ----------------
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+
+// ---- per-step constants of one env ---------------------------------------------------------------
+struct Control {
+    float tbx, tby, tbz;  // thrust in body frame (sim:167-175, :202-214: first gimbal column * T)
+    float thrust;         // N
+    float mdot;           // kg/s  (sim:140-141)
+};
+
+struct Inertia {          // sim:42-50, frozen at the episode's initial mass m0
+    float inv_jt;         // 1 / Jt
+    float jdiff;          // Jx - Jt
+};
+
+// env:509-521 -- no clipping of the normalised action
+__device__ __forceinline__ Control make_control_normalised(const R6Params& p, float a0, float a1, float a2) {
+    const float dy = a0 * p.max_gimbal;
+    const float dz = a1 * p.max_gimbal;
+    const float thr = (a2 + 1.0f) * 0.5f * p.max_thrust;
+    float sy, cy, sz, cz;
+    sincosf(dy, &sy, &cy);
+    sincosf(dz, &sz, &cz);
+    Control c;
+    c.tbx = thr * (cy * cz);
+    c.tby = thr * (sy * cz);
+    c.tbz = thr * sz;
+    c.thrust = thr;
+    c.mdot = thr * kMdotPerN;
+    return c;
+}
+
+__device__ __forceinline__ Control make_control_physical(float dy, float dz, float thr) {
+    float sy, cy, sz, cz;
+    sincosf(dy, &sy, &cy);
+    sincosf(dz, &sz, &cz);
+    Control c;
+    c.tbx = thr * (cy * cz);
+    c.tby = thr * (sy * cz);
+    c.tbz = thr * sz;
+    c.thrust = thr;
+    c.mdot = thr * kMdotPerN;
+    return c;
+}
+
+__device__ __forceinline__ Inertia make_inertia(float m0) {
+    Inertia j;
+    const float jt = m0 * kJtPerM;
+    j.inv_jt = 1.0f / jt;
+    j.jdiff = m0 * kJxPerM - jt;
+    return j;
+}
+
+// sim:145-150 -- rho0 * (Tb / (Tb + Lb h))^e  ==  rho0 * exp2(-e * log2(1 + (Lb/Tb) h))
+__device__ __forceinline__ float density(float h) {
+    const float base = fmaf(h, (float)(kLb / kTb), 1.0f);
+    return (float)kRho0 * fexp2((float)(-kRhoExp) * flog2(base));
+}
+
+// Dynamic part of the state: r(0..2) v(3..5) q(6..9) w(10..12).  Mass is linear in time (constant
+// mdot within a step, sim:140-141), so it is carried outside the RK stages.
+constexpr int kDyn = 13;
+
+// Rotation matrix body->inertial of q/|q| (sim:189-199; scipy normalises), written for a
+// non-unit quaternion: R = I + (2/|q|^2) * (...).
+struct Rot {
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+};
+
+__device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
+    const float n2 = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, q3 * q3)));
+    const float s = 2.0f * frcp(n2);
+    const float s1 = s * q1, s2 = s * q2, s3 = s * q3;
+    const float w1 = s1 * q0, w2 = s2 * q0, w3 = s3 * q0;
+    const float x1 = s1 * q1, x2 = s2 * q1, x3 = s3 * q1;
+    const float y2 = s2 * q2, y3 = s3 * q2, z3 = s3 * q3;
+    Rot R;
+    R.r00 = 1.0f - (y2 + z3);
+    R.r01 = x2 - w3;
+    R.r02 = x3 + w2;
+    R.r10 = x2 + w3;
+    R.r11 = 1.0f - (x1 + z3);
+    R.r12 = y3 - w1;
+    R.r20 = x3 - w2;
+    R.r21 = y3 + w1;
+    R.r22 = 1.0f - (x1 + y2);
+    return R;
+}
+
+// sim:106-143 -- derivative of the 13 dynamic components at mass `mass`.
+__device__ __forceinline__ void rhs13(const float (&y)[kDyn], float mass, const Control& c, const Inertia& J,
+                                      float (&dy)[kDyn]) {
+    const float vx = y[3], vy = y[4], vz = y[5];
+    const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
+    const float wx = y[10], wy = y[11], wz = y[12];
+    const Rot R = rotmat(q0, q1, q2, q3);
+
+    // aero (sim:216-219): A_B = -k rho |v| R^T v ; rotated back: A_I = -k rho |v| v
+    const float speed = fsqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+    const float ca = -kAeroK * density(y[0]) * speed;
+    const float aby = ca * fmaf(R.r01, vx, fmaf(R.r11, vy, R.r21 * vz));  // body-y aero force
+    const float abz = ca * fmaf(R.r02, vx, fmaf(R.r12, vy, R.r22 * vz));  // body-z aero force
+
+    // translational (sim:124-130, :156-165): F_I = R T_B + A_I
+    const float fx = fmaf(R.r00, c.tbx, fmaf(R.r01, c.tby, fmaf(R.r02, c.tbz, ca * vx)));
+    const float fy = fmaf(R.r10, c.tbx, fmaf(R.r11, c.tby, fmaf(R.r12, c.tbz, ca * vy)));
+    const float fz = fmaf(R.r20, c.tbx, fmaf(R.r21, c.tby, fmaf(R.r22, c.tbz, ca * vz)));
+    const float im = frcp(mass);
+    dy[0] = vx;
+    dy[1] = vy;
+    dy[2] = vz;
+    dy[3] = fmaf(fx, im, -(float)kG0);
+    dy[4] = fy * im;
+    dy[5] = fz * im;
+
+    // quaternion kinematics (sim:133-136, :221-229): qdot = 1/2 Omega(w) q
+    dy[6] = -0.5f * fmaf(wx, q1, fmaf(wy, q2, wz * q3));
+    dy[7] = 0.5f * fmaf(wx, q0, fmaf(wz, q2, -wy * q3));
+    dy[8] = 0.5f * fmaf(wy, q0, fmaf(-wz, q1, wx * q3));
+    dy[9] = 0.5f * fmaf(wz, q0, fmaf(wy, q1, -wx * q2));
+
+    // rotational (sim:137, :232-244): tau = r_T x T_B + r_cp x A_B with r = [rx,0,0]
+    //   -> tau = (0, -rT*tbz - rcp*abz, rT*tby + rcp*aby);  J = diag(Jx,Jt,Jt):
+    //   w x Jw = (0, (Jx-Jt) wx wz, (Jt-Jx) wx wy)  => wx is constant
+    const float tauy = fmaf(-(float)kArmThrust, c.tbz, -(float)kArmCp * abz);
+    const float tauz = fmaf((float)kArmThrust, c.tby, (float)kArmCp * aby);
+    const float g = J.jdiff * wx;
+    dy[10] = 0.0f;
+    dy[11] = (tauy - g * wz) * J.inv_jt;
+    dy[12] = (tauz + g * wy) * J.inv_jt;
+}
+
+template <int INTEG>
+__device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, const Control& c, const Inertia& J,
+                                         float h, float (&y1)[kDyn]) {
+    float k[kDyn];
+    if constexpr (INTEG == R6_EULER) {
+        rhs13(y0, mass, c, J, k);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h, k[i], y0[i]);
+    } else {
+        float acc[kDyn], yt[kDyn];
+        const float hh = 0.5f * h;
+        const float m_half = fmaf(-c.mdot, hh, mass);
+        const float m_full = fmaf(-c.mdot, h, mass);
+        rhs13(y0, mass, c, J, k);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) {
+            acc[i] = k[i];
+            yt[i] = fmaf(hh, k[i], y0[i]);
+        }
+        rhs13(yt, m_half, c, J, k);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) {
+            acc[i] = fmaf(2.0f, k[i], acc[i]);
+            yt[i] = fmaf(hh, k[i], y0[i]);
+        }
+        rhs13(yt, m_half, c, J, k);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) {
+            acc[i] = fmaf(2.0f, k[i], acc[i]);
+            yt[i] = fmaf(h, k[i], y0[i]);
+        }
+        rhs13(yt, m_full, c, J, k);
+        const float h6 = h * (1.0f / 6.0f);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h6, acc[i] + k[i], y0[i]);
+    }
+}
+
+// scipy find_active_events with direction == 0 (through sim:77-88)
+__device__ __forceinline__ bool crossing(float x_old, float x_new) {
+    return (x_old <= 0.0f && x_new >= 0.0f) || (x_old >= 0.0f && x_new <= 0.0f);
+}
+
+// theta in [0,1] with H(theta) = 0, H the cubic Hermite through (0,x0,d0), (1,x1,d1), d = h*vx.
+// Safeguarded Newton, fixed 8 iterations (same procedure as oracle/oracle_np.py hermite_root).
+__device__ __forceinline__ float hermite_root(float x0, float x1, float d0, float d1) {
+    if (x0 == 0.0f) return 0.0f;
+    if (x1 == 0.0f) return 1.0f;
+    const float c3 = 2.0f * x0 - 2.0f * x1 + d0 + d1;
+    const float c2 = -3.0f * x0 + 3.0f * x1 - 2.0f * d0 - d1;
+    float lo = 0.0f, hi = 1.0f;
+    float th = x0 / (x0 - x1);
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const float f = fmaf(fmaf(fmaf(c3, th, c2), th, d0), th, x0);
+        if (f == 0.0f) break;
+        if ((f > 0.0f) == (x0 > 0.0f)) lo = th; else hi = th;
+        const float df = fmaf(fmaf(3.0f * c3, th, 2.0f * c2), th, d0);
+        float nt = (df != 0.0f) ? th - f / df : 0.5f * (lo + hi);
+        if (!(nt > lo && nt < hi)) nt = 0.5f * (lo + hi);
+        th = nt;
+    }
+    return th;
+}
+
+// One env step of the simulator (sim:69-104) with fixed sub-steps.  Returns status (1 = ground).
+template <int INTEG>
+__device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J,
+                                         float dt, int nsub) {
+    const float h = dt / (float)nsub;
+    int status = 0;
+#pragma unroll 1
+    for (int s = 0; s < nsub; ++s) {
+        if (status == 0) {
+            float y1[kDyn];
+            step_map<INTEG>(y, mass, c, J, h, y1);
+            float hs = h;
+            if (crossing(y[0], y1[0])) {
+                float th;
+                if constexpr (INTEG == R6_RK4) {
+                    th = hermite_root(y[0], y1[0], h * y[3], h * y1[3]);
+                } else {
+                    th = (y[0] == 0.0f) ? 0.0f : y[0] / (y[0] - y1[0]);
+                }
+                hs = th * h;
+                step_map<INTEG>(y, mass, c, J, hs, y1);
+                status = 1;
+            }
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) y[i] = y1[i];
+            mass = fmaf(-c.mdot, hs, mass);
+        }
+    }
+    // sim:97, :153-154 -- quaternion renormalised after the step
+    const float n2 = fmaf(y[6], y[6], fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
+    const float inv = frsq(n2);
+    y[6] *= inv;
+    y[7] *= inv;
+    y[8] *= inv;
+    y[9] *= inv;
+    return status;
+}
+
+// ---- reward (env:317-402) ------------------------------------------------------------------------
+
+// env:528-546 -- t_go = largest positive real root of  g^2 t^4 + c2 t^2 + c1 t + c0,
+// c2 = -4|v|^2 <= 0, c1 = -24 r.v, c0 = -36|r|^2 <= 0.  (np.roots order + "first positive real"
+// selects the largest positive real root: 38k multi-root cases checked in the build container and
+// golden G5.)  Structure: p is convex for t > ti = sqrt(-c2/(6 g^2)) and concave on [0, ti].
+//   * Newton from an upper bound walks down the convex branch monotonically to the largest root;
+//   * if it runs out of the convex branch with p > 0 (no root there) the root is the single
+//     crossing of the concave branch, reached monotonically by Newton from t = 0 (p(0) = c0 < 0).
+// fp32 iterations, then one Newton correction with the residual evaluated in fp64.
+__device__ __forceinline__ float t_go_quartic(float c2, float c1, float c0) {
+    constexpr float g2 = (float)(kGShaping * kGShaping);
+    constexpr float ig2 = (float)(1.0 / (kGShaping * kGShaping));
+    const float b2 = c2 * ig2, b1 = c1 * ig2, b0 = c0 * ig2;  // monic
+    // Fujiwara bound on every root modulus: 2 max(|b2|^(1/2), |b1|^(1/3), |b0/2|^(1/4))
+    const float m2 = fsqrt(fabsf(b2));
+    const float m1 = fexp2(flog2(fmaxf(fabsf(b1), 1e-30f)) * (1.0f / 3.0f));
+    const float m0 = fsqrt(fsqrt(0.5f * fabsf(b0)));
+    const float ti = fsqrt(fabsf(b2) * (1.0f / 6.0f));
+    float t = 2.002f * fmaxf(m2, fmaxf(m1, m0)) + 1e-6f;
+    bool left = false;  // false: descending the convex branch; true: ascending the concave one
+#pragma unroll 1
+    for (int it = 0; it < 24; ++it) {
+        const float t2 = t * t;
+        const float p = fmaf(fmaf(t2 + b2, t, b1), t, b0);
+        const float dp = fmaf(fmaf(4.0f, t2, 2.0f * b2), t, b1);
+        if (!left) {
+            if (p <= 0.0f) {
+                left = true;  // at / just left of the root: finish monotonically from the left
+            } else if (dp <= 0.0f || t < ti) {
+                left = true;  // p > 0 but off the convex branch: no root there, restart at t = 0
+                t = 0.0f;
+                continue;
+            }
+        }
+        float tn = t - p * frcp(dp);
+        if (left) tn = fmaxf(tn, t);           // monotone from the left (guards round-off)
+        else tn = fminf(tn, t);                // monotone from the right
+        if (!(tn >= 0.0f)) tn = 0.0f;
+        const bool conv = fabsf(tn - t) <= 2e-7f * fabsf(tn);
+        t = tn;
+        if (__all(conv)) break;
+    }
+    // fp64 polish on the un-normalised polynomial (coefficients as the reference hands them to
+    // np.roots: float32 values promoted to float64)
+    const double td = (double)t;
+    const double pd = fma(fma(fma((double)g2 * td, td, (double)c2), td, (double)c1), td, (double)c0);
+    const float dpf = fmaf(fmaf(4.0f * g2, t * t, 2.0f * c2), t, c1);
+    const float corr = (float)pd * frcp(dpf);
+    return (dpf > 0.0f) ? t - corr : t;
+}
+
+struct RewardOut {
+    float terms[R6_NUM_TERMS];
+    float sum;
+    bool landed;  // all landing conditions of env:382-390 hold
+};
+
+// env:317-402 on the fp32 post-step state; `c` is the control applied during the step (env:339 and
+// sim:177-186 use the post-step attitude with the current action).
+template <int SHAPING>
+__device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[kDyn], float mass, const Control& c,
+                                            float v0) {
+    RewardOut o;
+    const float rx = y[0], ry = y[1], rz = y[2];
+    const float vx = y[3], vy = y[4], vz = y[5];
+    const Rot R = rotmat(y[6], y[7], y[8], y[9]);
+    const float vv = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
+    const float rr = fmaf(rx, rx, fmaf(ry, ry, rz * rz));
+    const float vn = fsqrt(vv);
+    const float rn = fsqrt(rr);
+
+    float track;
+    if constexpr (SHAPING == R6_SHAPING_ACCELERATION) {
+        // env:526-566
+        const float rv = fmaf(rx, vx, fmaf(ry, vy, rz * vz));
+        const float tgo = t_go_quartic(-4.0f * (vn * vn), -24.0f * rv, -36.0f * (rn * rn));
+        const float it = frcp(tgo);
+        const float k6 = -6.0f * it * it, k4 = -4.0f * it;
+        float ax = fmaf(k6, rx, fmaf(k4, vx, (float)kGShaping));  // - g,  g = [-9.81,0,0]
+        float ay = fmaf(k6, ry, k4 * vy);
+        float az = fmaf(k6, rz, k4 * vz);
+        const float an = fsqrt(fmaf(ax, ax, fmaf(ay, ay, az * az)));
+        const float im = frcp(mass);
+        const float lim = p.max_thrust * im;                      // env:562
+        if (!(an <= lim)) {
+            const float sc = lim / an;
+            ax *= sc;
+            ay *= sc;
+            az *= sc;
+        }
+        // env:339-340: a = R(q_post) T_B / m
+        const float tx = fmaf(R.r00, c.tbx, fmaf(R.r01, c.tby, R.r02 * c.tbz)) * im - ax;
+        const float ty = fmaf(R.r10, c.tbx, fmaf(R.r11, c.tby, R.r12 * c.tbz)) * im - ay;
+        const float tz = fmaf(R.r20, c.tbx, fmaf(R.r21, c.tby, R.r22 * c.tbz)) * im - az;
+        track = p.alfa * fsqrt(fmaf(tx, tx, fmaf(ty, ty, tz * tz)));
+    } else {
+        // env:646-674
+        float hx, hy, hz, ux, tau;
+        if (rx > p.waypoint) {
+            hx = rx - p.waypoint; hy = ry; hz = rz; ux = vx + 2.0f; tau = 20.0f;
+        } else {
+            hx = rx + 1.0f; hy = 0.0f; hz = 0.0f; ux = vx + 1.0f; tau = 100.0f;
+        }
+        const float hn = fsqrt(fmaf(hx, hx, fmaf(hy, hy, hz * hz)));
+        const float un = fsqrt(fmaf(ux, ux, fmaf(vy, vy, vz * vz)));
+        const float tgo = hn / un;
+        const float g = -v0 * (1.0f - expf(-tgo / tau)) / fmaxf(1e-3f, hn);
+        const float dx = vx - g * hx, dy = vy - g * hy, dz = vz - g * hz;
+        track = p.alfa * fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+    }
+
+    // env:366-369 / :386-388 -- Euler zyx limits without inverse trig (see r6dof.h)
+    const float h0 = fsqrt(fmaf(R.r00, R.r00, R.r01 * R.r01));
+    const float h2 = fsqrt(fmaf(R.r22, R.r22, R.r12 * R.r12));
+    const float a1 = fabsf(R.r02);
+    const bool exceed = (R.r00 < p.traj_c0 * h0) || (a1 > p.traj_s1) || (R.r22 < p.traj_c2 * h2);
+    const bool att_ok = (R.r00 > p.land_c0 * h0) || (a1 < p.land_s1) || (R.r22 > p.land_c2 * h2);
+
+    // env:371-402
+    const bool zero_h = rx <= 1e-3f;
+    const bool om_ok = (fabsf(y[10]) < p.omega_lim[0]) || (fabsf(y[11]) < p.omega_lim[1]) ||
+                       (fabsf(y[12]) < p.omega_lim[2]);
+    const bool landed = zero_h && (vn < p.land_vmax) && (rn < p.land_radius) && att_ok && om_ok;
+
+    o.terms[0] = track;
+    o.terms[1] = p.beta * c.thrust;                                   // env:355
+    o.terms[2] = p.eta;                                               // env:356
+    o.terms[3] = exceed ? p.gamma : 0.0f;                             // env:357
+    o.terms[4] = landed ? p.kappa : 0.0f;                             // env:399
+    o.terms[5] = fmaxf(p.max_r_f - rn, 0.0f) * p.w_r_f;               // env:400
+    o.terms[6] = (rn < p.max_r_f && zero_h) ? fmaxf(p.max_v_f - vn, 0.0f) * p.w_v_f : 0.0f;  // env:401
+    o.landed = landed;
+    o.sum = ((((((o.terms[0] + o.terms[1]) + o.terms[2]) + o.terms[3]) + o.terms[4]) + o.terms[5]) + o.terms[6]);
+    return o;
+}
+
+// env:591-593 -- inclusive float32 box; NaN counts as a violation (Box.contains is False).
+__device__ __forceinline__ bool bounds_violation(const R6Params& p, float x, float y, float z) {
+    const bool inside = (x >= p.bound_lo[0]) && (x <= p.bound_hi[0]) && (y >= p.bound_lo[1]) &&
+                        (y <= p.bound_hi[1]) && (z >= p.bound_lo[2]) && (z <= p.bound_hi[2]);
+    return !inside;
+}
+
+// ---- counter-based reset RNG: Philox-4x32-10 ------------------------------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// env:180-199 -- initial condition of global env `gid` reset at global step `step_index`
+// (same stream definition as oracle_np.reset_sample).  Returns the 14-vector, quaternion normalised.
+__device__ __forceinline__ void sample_ic(const R6Params& p, uint64_t seed, uint64_t gid, uint64_t step_index,
+                                          float (&ic)[R6_STATE_DIM]) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t w[16];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+        const U4 r = philox4x32_10(U4{(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step_index,
+                                      ((uint32_t)(step_index >> 32) & 0x3FFFFFFFu) | (b << 30)},
+                                   k0, k1);
+        w[4 * b + 0] = r.x;
+        w[4 * b + 1] = r.y;
+        w[4 * b + 2] = r.z;
+        w[4 * b + 3] = r.w;
+    }
+#pragma unroll
+    for (int j = 0; j < R6_STATE_DIM; ++j) {
+        const float u = (float)(w[j] >> 8) * 5.9604644775390625e-08f;  // 2^-24
+        ic[j] = fmaf(u, p.ic_range[j], p.ic_lo[j]);
+    }
+    const float n2 = fmaf(ic[6], ic[6], fmaf(ic[7], ic[7], fmaf(ic[8], ic[8], ic[9] * ic[9])));
+    const float inv = 1.0f / sqrtf(n2);
+    ic[6] *= inv;
+    ic[7] *= inv;
+    ic[8] *= inv;
+    ic[9] *= inv;
+}
+
+}  // namespace r6

@@ -1,0 +1,81 @@
+"""Multi-GPU: one process per GPU, environments sharded embarrassingly, no collective in ``step``.
+
+The reference has no parallelism of any kind (n_envs = 1, main_6DOF.py:105-114); this is the build's
+data-parallel layer.  Rank r of W owns the global envs [offset_r, offset_r + count_r); the reset RNG
+is keyed by the GLOBAL env index, so a W-GPU run visits exactly the states of a 1-GPU run.  The one
+collective -- an all-gather of a fixed-size per-rank episode summary, once per rollout -- goes through
+``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on ROCm; ``gloo`` on CPU for tests).  The
+message is NUM_STATS float64 per rank: latency-bound, nowhere near xGMI link bandwidth.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .params import NUM_STATS, STAT_NAMES
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """(offset, count) of rank's contiguous shard; counts differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("need 0 <= rank < world")
+    q, r = divmod(total, world)
+    count = q + (1 if rank < r else 0)
+    offset = rank * q + min(rank, r)
+    return offset, count
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialises torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank); no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str, float], torch.Tensor]:
+    """All-gathers the per-rank episode summaries (``BatchedRocket6DOF.episode_stats()``).
+    Returns (global totals, per-rank table [world, NUM_STATS])."""
+    vec = torch.tensor([local[k] for k in STAT_NAMES], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            vec = vec.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        table = torch.empty((dist.get_world_size(), NUM_STATS), dtype=torch.float64, device=vec.device)
+        dist.all_gather_into_tensor(table, vec)
+        table = table.cpu()
+    else:
+        table = vec.reshape(1, NUM_STATS)
+    tot = table.sum(0)
+    return {k: float(tot[i]) for i, k in enumerate(STAT_NAMES)}, table
+
+
+def summarize(tot: Dict[str, float]) -> Dict[str, float]:
+    n = max(tot["episodes"], 1.0)
+    mean = tot["return_sum"] / n
+    var = max(tot["return_sq_sum"] / n - mean * mean, 0.0)
+    return {"episodes": tot["episodes"], "ep_rew_mean": mean, "ep_rew_std": var ** 0.5,
+            "ep_len_mean": tot["length_sum"] / n, "ground_frac": tot["ground"] / n,
+            "bounds_frac": tot["bounds"] / n, "truncated_frac": tot["truncated"] / n,
+            "landed_frac": tot["landed"] / n}
+
+
+def make_sharded_env(total_envs: int, env_config=None, **kwargs):
+    """This rank's shard of a ``total_envs``-wide job as a ``BatchedRocket6DOF`` (env_offset set)."""
+    from .batched_env import BatchedRocket6DOF
+
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    offset, count = shard_range(total_envs, rank, world)
+    return BatchedRocket6DOF(count, env_config, env_offset=offset, **kwargs)

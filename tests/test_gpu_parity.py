@@ -1,0 +1,365 @@
+"""GPU parity tests proper: the HIP path (through the C ABI / BatchedRocket6DOF) against
+  (1) the golden vectors recorded from the reference itself (tests/golden/*.npz), and
+  (2) the CPU oracle (oracle/oracle_np.py) on seeded inputs.
+
+Tolerance (BASELINE.json north_star): per-step outputs within 1e-5 relative fp32, done masks
+bit-exact.  "Relative" is taken against max(|reference|, natural scale) where the natural scale of a
+state component is the reference's own observation normaliser (so the test is a 1e-5 bound on the
+normalised observation error), of a reward term 1e-1 (the per-step `eta` bonus), of the total reward 1.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+TERM_SCALE = 1e-1
+REWARD_SCALE = 1.0
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test running without a GPU")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return json.loads(str(load_golden("g3_env_rollouts.npz")["config"]))
+
+
+@pytest.fixture(scope="module")
+def P(cfg):
+    from oracle import oracle_np as onp
+
+    return onp.OracleParams.from_config(cfg)
+
+
+def _teacher_forced(torch, cfg, G, **kw):
+    """Every recorded reference step becomes one env of a single launch."""
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n = len(G["reward"])
+    env = BatchedRocket6DOF(n, cfg, auto_reset=False, record_terms=True, **kw)
+    env.set_state(G["pre"].astype(np.float32), m0=G["m0"].astype(np.float32))
+    obs, rew, done, infos = env.step(torch.as_tensor(G["action"], device=env.device))
+    torch.cuda.synchronize()
+    return env, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), infos
+
+
+def _check_against_golden(env, obs, rew, done, G, P, what):
+    flags = env.flags.cpu().numpy()
+    np.testing.assert_array_equal(done.astype(np.uint8), G["done"], err_msg=f"{what}: done mask")
+    np.testing.assert_array_equal((flags & 2) >> 1, G["bounds"], err_msg=f"{what}: bounds flag")
+    np.testing.assert_array_equal(flags & 1, (G["status"] == 1).astype(np.uint8), err_msg=f"{what}: ground-event status")
+    post = env.get_state().cpu().numpy()
+    e_state = assert_close_scaled(post, G["post"], P.normalizer[None, :], RTOL, f"{what}: post-state")
+    e_obs = assert_close_scaled(obs, G["obs"], 1.0, RTOL, f"{what}: observation")
+    terms = env.terms[:, : env.num_envs].t().cpu().numpy()
+    e_terms = assert_close_scaled(terms, G["terms"], TERM_SCALE, RTOL, f"{what}: reward terms")
+    e_rew = assert_close_scaled(rew, G["reward"], REWARD_SCALE, RTOL, f"{what}: reward")
+    print(f"[{what}] n={len(rew)} worst scaled err: state {e_state:.2e} obs {e_obs:.2e} terms {e_terms:.2e} reward {e_rew:.2e}")
+    return e_state, e_obs, e_terms, e_rew
+
+
+def test_g2_rhs_known_answers(torch_cuda):
+    """Simulator6DOF.RHS (simulator.py:106-143) on 512 random (y,u), un-normalised quaternions."""
+    import ctypes as C
+
+    from rl_rocket_6dof_amd import _lib
+    from rl_rocket_6dof_amd.params import R6Params
+
+    torch = torch_cuda
+    g2 = load_golden("g2_rhs.npz")
+    n = len(g2["y"])
+    ld = (n + 63) // 64 * 64
+    dev = "cuda:0"
+    y = torch.zeros((14, ld), device=dev)
+    y[:, :n] = torch.as_tensor(g2["y"].T.astype(np.float32))
+    ep = torch.zeros((2, ld), device=dev)
+    ep[0, :n] = torch.as_tensor(g2["m0"].astype(np.float32))
+    u = torch.as_tensor(g2["u"], device=dev).contiguous()
+    dy = torch.zeros((14, ld), device=dev)
+    lib = _lib.load()
+    p = R6Params()
+    rc = lib.r6_rhs(C.byref(p), y.data_ptr(), ep.data_ptr(), u.data_ptr(), dy.data_ptr(), n, ld, None)
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    got = dy[:, :n].t().cpu().numpy()
+    # derivative scales: velocities ~1e2 m/s, accelerations ~1e1, qdot ~1, wdot ~1, mdot ~1e2
+    scale = np.array([100, 100, 100, 10, 10, 10, 1, 1, 1, 1, 1, 1, 1, 100.0])
+    err = assert_close_scaled(got, g2["dy"], scale[None, :], RTOL, "RHS vs golden G2")
+    print(f"[G2] worst scaled err {err:.2e}")
+
+
+def test_g1_simulator_smoke_case(torch_cuda):
+    """test_6DOF_simulator.py:3-7 through the Simulator6DOF drop-in (dt = 0.5 -> 5 RK4 sub-steps)."""
+    from rl_rocket_6dof_amd import Simulator6DOF
+
+    g1 = load_golden("g1_sim_step.npz")
+    sim = Simulator6DOF(list(g1["ic"]))          # default dt 0.5 like the reference
+    state, status = sim.step(list(g1["u"]))
+    assert status == int(g1["status"]) == 0
+    scale = np.array([100, 100, 100, 5, 5, 5, 1, 1, 1, 1, 1e-2, 1e-2, 1e-2, 5e4])
+    assert_close_scaled(state, g1["state"], scale, RTOL, "G1 Simulator6DOF.step")
+    assert sim.t == 0.5 and len(sim.states) == 2 and len(sim.times) == 2
+
+
+@pytest.mark.parametrize("fixture", ["g3_env_rollouts.npz", "g4_ground_events.npz"])
+def test_env_step_teacher_forced_vs_reference(torch_cuda, cfg, P, fixture):
+    """Rocket6DOF.step (rocket_env.py:201-231), every recorded reference step restarted from the
+    reference's own pre-state: post-state, obs, 7 reward terms, reward within 1e-5; done, bounds and
+    ground-event masks bit-exact."""
+    G = load_golden(fixture)
+    env, obs, rew, done, _ = _teacher_forced(torch_cuda, cfg, G)
+    _check_against_golden(env, obs, rew, done, G, P, fixture)
+
+
+def test_g5_reward_known_answers(torch_cuda, cfg, P):
+    """_compute_reward / _reward_goal / _check_attitude_limits / _check_bounds_violation
+    (rocket_env.py:317-402, :591-593) on crafted post-states.  The kernel only evaluates the reward
+    after a step, so the step is made degenerate (dt = 1e-9 s: the state does not move in fp32)."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    g5 = load_golden("g5_reward_cases.npz")
+    S = g5["state"].astype(np.float32)
+    n = len(S)
+    env = BatchedRocket6DOF(n, cfg, auto_reset=False, record_terms=True, timestep=1e-9, n_substeps=1)
+    env.set_state(S)
+    obs, rew, done, _ = env.step(torch.as_tensor(g5["action"], device=env.device))
+    torch.cuda.synchronize()
+    flags = env.flags.cpu().numpy()
+    np.testing.assert_array_equal((flags & 2) >> 1, g5["bounds"], err_msg="bounds flag")
+    terms = env.terms[:, :n].t().cpu().numpy()
+    # discrete terms (attitude, goal) must agree exactly in which cases fire
+    np.testing.assert_array_equal(terms[:, 3] != 0, g5["terms"][:, 3] != 0, err_msg="attitude_constraint cases")
+    np.testing.assert_array_equal(terms[:, 4] != 0, g5["terms"][:, 4] != 0, err_msg="goal_conditions cases")
+    np.testing.assert_array_equal(terms[:, 6] != 0, g5["terms"][:, 6] != 0, err_msg="final_velocity cases")
+    e = assert_close_scaled(terms, g5["terms"], TERM_SCALE, RTOL, "G5 reward terms")
+    want = g5["reward_sum"] + np.where(g5["bounds"] == 1, -50.0, 0.0)
+    assert_close_scaled(rew.cpu().numpy(), want, REWARD_SCALE, RTOL, "G5 reward")
+    print(f"[G5] n={n} worst scaled term err {e:.2e}")
+
+
+def test_g3_free_running_episodes(torch_cuda, cfg, P):
+    """Whole reference episodes replayed open-loop in fp32 from the recorded x0 with the recorded
+    actions: the episode must end on the same step for the same reason; trajectory drift (fp32
+    accumulation vs the reference's float64) is reported and bounded at 1e-4 scaled."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    G = load_golden("g3_env_rollouts.npz")
+    eps = np.unique(G["episode"])
+    n = len(eps)
+    env = BatchedRocket6DOF(n, cfg, auto_reset=False, record_terms=False)
+    env.set_state(G["x0"].astype(np.float32))
+    lens = np.array([(G["episode"] == e).sum() for e in eps])
+    starts = np.array([np.nonzero(G["episode"] == e)[0][0] for e in eps])
+    worst = 0.0
+    for k in range(lens.max()):
+        act = np.zeros((n, 3), np.float32)
+        alive = k < lens
+        act[alive] = G["action"][starts[alive] + k]
+        obs, rew, done, _ = env.step(torch.as_tensor(act, device=env.device))
+        obs, done = obs.cpu().numpy(), done.cpu().numpy()
+        for e in np.nonzero(alive)[0]:
+            i = starts[e] + k
+            assert bool(done[e]) == bool(G["done"][i]), f"episode {e} step {k}: done {done[e]} vs {G['done'][i]}"
+            worst = max(worst, assert_close_scaled(obs[e], G["obs"][i], 1.0, 1e-4, f"episode {e} step {k} obs"))
+    print(f"[G3 free-running] {n} episodes, {int(lens.sum())} steps, worst scaled obs drift {worst:.2e}")
+
+
+@pytest.mark.parametrize("name,integ,h", [("euler_0.04", "euler", 0.04), ("euler_0.1", "euler", 0.1),
+                                           ("rk4_0.04", "rk4", 0.04), ("rk4_0.1", "rk4", 0.1)])
+def test_g6_fixed_step_maps(torch_cuda, cfg, P, name, integ, h):
+    """Reference RHS + textbook Euler / RK4 single steps (the parity oracle of BASELINE configs 2-3)."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    g6 = load_golden("g6_fixed_step.npz")
+    n = len(g6["pre"])
+    env = BatchedRocket6DOF(n, cfg, auto_reset=False, integrator=integ, timestep=h, n_substeps=1)
+    env.set_state(g6["pre"].astype(np.float32), m0=g6["m0"].astype(np.float32))
+    env.step(torch.as_tensor(g6["action"], device=env.device))
+    got = env.get_state().cpu().numpy().astype(np.float64)
+    want = g6[f"single_{name}"].copy()
+    want[:, 6:10] /= np.linalg.norm(want[:, 6:10], axis=1, keepdims=True)   # the kernel renormalises (simulator.py:97)
+    e = assert_close_scaled(got, want, P.normalizer[None, :], RTOL, f"G6 {name}")
+    print(f"[G6 {name}] worst scaled err {e:.2e}")
+
+
+@pytest.mark.parametrize("name,integ,h", [("euler_0.04", "euler", 0.04), ("rk4_0.04", "rk4", 0.04), ("rk4_0.1", "rk4", 0.1)])
+def test_g6_free_running_rollouts(torch_cuda, cfg, P, name, integ, h):
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    g6 = load_golden("g6_fixed_step.npz")
+    ys = [g6[f"roll_{name}_{r}_states"] for r in range(2)]
+    acts = [g6[f"roll_{name}_{r}_actions"] for r in range(2)]
+    env = BatchedRocket6DOF(2, cfg, auto_reset=False, integrator=integ, timestep=h, n_substeps=1)
+    env.set_state(np.stack([y[0] for y in ys]).astype(np.float32))
+    nmax = max(len(a) for a in acts)
+    worst = 0.0
+    for k in range(nmax):
+        a = np.zeros((2, 3), np.float32)
+        for r in range(2):
+            if k < len(acts[r]):
+                a[r] = acts[r][k]
+        env.step(torch.as_tensor(a, device=env.device))
+        st = env.get_state().cpu().numpy()
+        for r in range(2):
+            if k < len(acts[r]):
+                worst = max(worst, assert_close_scaled(st[r], ys[r][k + 1], P.normalizer, 1e-4, f"{name} rollout {r} step {k}"))
+    print(f"[G6 rollout {name}] worst scaled drift over {nmax} steps {worst:.2e}")
+
+
+def test_velocity_shaping_vs_oracle(torch_cuda, cfg):
+    """reward_shaping_type == 'velocity' (rocket_env.py:345-350, :646-674) against the CPU oracle."""
+    torch = torch_cuda
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    vcfg = json.loads(json.dumps(cfg))
+    vcfg["reward_shaping_type"] = "velocity"
+    vcfg["landing_params"]["waypoint"] = 50
+    G = load_golden("g3_env_rollouts.npz")
+    idx = np.arange(0, len(G["reward"]), 7)
+    G4 = load_golden("g4_ground_events.npz")
+    pre = np.concatenate([G["pre"][idx], G4["pre"][::5]])
+    m0 = np.concatenate([G["m0"][idx], G4["m0"][::5]])
+    act = np.concatenate([G["action"][idx], G4["action"][::5]])
+    v0 = np.linalg.norm(pre[:, 3:6], axis=1) * 1.1
+    n = len(pre)
+    env = BatchedRocket6DOF(n, vcfg, auto_reset=False, record_terms=True)
+    env.set_state(pre.astype(np.float32), m0=m0.astype(np.float32), v0=v0.astype(np.float32))
+    obs, rew, done, _ = env.step(torch.as_tensor(act, device=env.device))
+    terms = env.terms[:, :n].t().cpu().numpy()
+    Pv = onp.OracleParams.from_config(vcfg)
+    for i in range(n):
+        o = onp.env_step(pre[i].astype(np.float32).astype(np.float64), float(np.float32(m0[i])), act[i], Pv, "rk4",
+                         v0=float(np.float32(v0[i])))
+        assert bool(done[i]) == o["done"]
+        assert_close_scaled(terms[i], o["terms"], TERM_SCALE, RTOL, f"velocity shaping terms {i}")
+
+
+def test_reset_matches_oracle_stream(torch_cuda, cfg, P):
+    """Rocket6DOF.reset (rocket_env.py:180-199): the Philox initial-condition stream is bit-identical
+    to the oracle's for the 10 plain components; the quaternion (normalised in fp32) to 1 ulp."""
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.batched_env import _EXPLICIT_RESET_BASE
+
+    n = 777
+    env = BatchedRocket6DOF(n, cfg, seed=1234, env_offset=10_000_000_000)
+    obs = env.reset().cpu().numpy()
+    st = env.get_state().cpu().numpy()
+    plain = [0, 1, 2, 3, 4, 5, 10, 11, 12, 13]
+    for i in range(0, n, 37):
+        want = onp.reset_sample(1234, 10_000_000_000 + i, _EXPLICIT_RESET_BASE, P)
+        np.testing.assert_array_equal(st[i, plain], want[plain])
+        np.testing.assert_allclose(st[i, 6:10], want[6:10], rtol=0, atol=1.2e-7)
+        np.testing.assert_allclose(obs[i], want / P.normalizer, rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(env.epconst[0, :n].cpu().numpy(), st[:, 13])
+    np.testing.assert_allclose(env.epconst[1, :n].cpu().numpy(), np.linalg.norm(st[:, 3:6], axis=1), rtol=1e-6)
+    st2 = env.reset(), env.get_state().cpu().numpy()
+    assert not np.array_equal(st, st2[1]), "second reset must draw new initial conditions"
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 255, 256, 257, 1000])
+def test_ragged_sizes_match_full_batch(torch_cuda, cfg, n):
+    """Ragged / tiny batches (partial workgroups take the scalar edge path) give the same answers as
+    the same envs inside a large batch."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    G = load_golden("g3_env_rollouts.npz")
+    big = BatchedRocket6DOF(1024, cfg, auto_reset=False, record_terms=True)
+    pre = np.resize(G["pre"], (1024, 14)).astype(np.float32)
+    act = np.resize(G["action"], (1024, 3)).astype(np.float32)
+    m0 = np.resize(G["m0"], 1024).astype(np.float32)
+    big.set_state(pre, m0=m0)
+    bo, br, bd, _ = big.step(torch.as_tensor(act, device=big.device))
+    small = BatchedRocket6DOF(n, cfg, auto_reset=False, record_terms=True)
+    small.set_state(pre[:n], m0=m0[:n])
+    so, sr, sd, _ = small.step(torch.as_tensor(act[:n], device=small.device))
+    assert torch.equal(so, bo[:n]) and torch.equal(sr, br[:n]) and torch.equal(sd, bd[:n])
+    assert torch.equal(small.get_state(), big.get_state()[:n])
+
+
+def test_wrapped_variant_timelimit_clip_removemass(torch_cuda, cfg):
+    """Fused make_env() stack (main_6DOF.py:44-53): RemoveMassFromObs, ClipReward(-1,100),
+    TimeLimit, Monitor episode stats, auto-reset with terminal_observation."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n, T = 512, 40
+    env = BatchedRocket6DOF(n, cfg, remove_mass=True, clip_reward=(-1, 100), max_episode_steps=T, seed=7)
+    raw = BatchedRocket6DOF(n, cfg, auto_reset=False, seed=7, record_terms=True)
+    obs0 = env.reset()
+    raw.reset()
+    assert obs0.shape == (n, 13)
+    assert torch.equal(env.get_state(), raw.get_state())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    ret = torch.zeros(n)
+    for k in range(T):
+        a = (torch.rand((n, 3), generator=g) * 2 - 1).to(env.device)
+        pre_state = env.get_state().clone()
+        m0_pre = env.epconst[0, :n].clone()
+        obs, rew, done, infos = env.step(a)
+        raw.set_state(pre_state, m0=m0_pre)
+        ro, rr, rd, _ = raw.step(a)
+        # reward is the clipped raw reward; obs is the first 13 entries (where no reset happened)
+        assert torch.equal(rew, rr.clamp(-1, 100))
+        nd = ~done
+        assert torch.equal(obs[nd], ro[nd][:, :13])
+        ret += rew.cpu()
+        if k < T - 1:
+            assert torch.equal(done, rd), "before the limit only env terminations end episodes"
+        else:
+            assert bool(done.all()), "TimeLimit ends every remaining episode at max_episode_steps"
+            fl = env.flags.cpu().numpy()
+            trunc = (fl & 4) != 0
+            np.testing.assert_array_equal(trunc, ~rd.cpu().numpy())
+        d = done.cpu().numpy()
+        for i in np.nonzero(d)[0][:5]:
+            info = infos[int(i)]
+            np.testing.assert_array_equal(info["terminal_observation"], ro[i, :13].cpu().numpy())
+            assert info["episode"]["l"] >= 1 and "TimeLimit.truncated" in info
+    stats = env.episode_stats()
+    assert stats["episodes"] >= n and stats["length_sum"] == T * n
+    assert abs(stats["return_sum"] - float(ret.sum())) < 1e-3 * max(1.0, abs(float(ret.sum())))
+    assert stats["truncated"] + stats["ground"] + stats["bounds"] >= stats["episodes"]
+
+
+def test_single_env_surface(torch_cuda, cfg):
+    """gym-0.21 surface of Rocket6DOF (what SB3's check_env exercises, test_6DOF_sb_integration.py:24)."""
+    from rl_rocket_6dof_amd import Rocket6DOF
+
+    env = Rocket6DOF(**cfg)
+    obs = env.reset()
+    assert obs.dtype == np.float32 and obs.shape == (14,)
+    assert env.observation_space.shape == (14,) and env.action_space.shape == (3,)
+    G = load_golden("g3_env_rollouts.npz")
+    ep0 = G["episode"] == 0
+    obs = env.reset_to(G["x0"][0])
+    total = 0.0
+    for k, i in enumerate(np.nonzero(ep0)[0]):
+        obs, rew, done, info = env.step(G["action"][i])
+        assert isinstance(rew, float) and isinstance(done, bool) and isinstance(info, dict)
+        assert obs.dtype == np.float32 and obs.shape == (14,)
+        for key in ("rewards_dict", "is_done", "state_history", "action_history", "timesteps", "bounds_violation",
+                    "atarg_tracking", "final_velocity"):
+            assert key in info
+        assert done == bool(G["done"][i])
+        assert_close_scaled(obs, G["obs"][i], 1.0, 1e-4, f"single-env obs step {k}")
+        total += rew
+    assert done and len(env.SIM.states) == ep0.sum() + 1 and env.SIM.t == round(0.1 * ep0.sum(), 3)
+    env.close()
