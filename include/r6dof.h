@@ -55,7 +55,8 @@ enum {
     R6_STAT_TRUNCATED = 6,/* episodes ended by the time limit */
     R6_STAT_LANDED = 7    /* episodes whose last step met all landing conditions (goal term) */
 };
-#define R6_BLOCK 256      /* environments per workgroup (rows of `stats` = ceil(n / R6_BLOCK)) */
+#define R6_BLOCK 256      /* threads per workgroup (4 wave64) */
+#define R6_MAX_BLOCKS 2048 /* upper bound of the persistent step grid = rows of `stats` */
 
 /* Kernel constants: everything config.yaml's env_config can change (rocket_env.py:22-178),
  * pre-digested on the host.  All members are 4 bytes wide (no padding anywhere). */
@@ -119,8 +120,9 @@ typedef struct R6Buffers {
     float *ep_return;     /* [n]       in/out: running episode return (Monitor) */
     float *fin_return;    /* [n]       out at done: episode return */
     uint32_t *fin_length; /* [n]       out at done: episode length */
-    float *stats;         /* [ceil(n/256)][R6_NUM_STATS] in/out: per-workgroup running sums over
-                                       finished episodes (see R6_STAT_*); deterministic, no atomics */
+    float *stats;         /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out: per-workgroup running sums over
+                                       finished episodes (see R6_STAT_*); no float atomics; the
+                                       caller sums the rows */
 } R6Buffers;
 
 int r6_abi_version(void);

@@ -10,7 +10,7 @@ import os
 from .params import R6Buffers, R6Params
 
 ABI_VERSION = 1
-_LIB = None
+_LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs")
@@ -24,21 +24,21 @@ def lib_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libr6dof.so")
 
 
-def load():
-    """Loads (once) and returns the ctypes handle."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
+def load(path: str | None = None):
+    """Loads (once per path) and returns the ctypes handle.  ``path`` defaults to the in-tree
+    library; other paths are for A/B-ing kernel builds in one process (scripts/kbench.py)."""
+    path = os.path.abspath(path or os.environ.get("R6_LIB", lib_path()))
+    if path in _LIBS:
+        return _LIBS[path]
     # torch first: its bundled libamdhip64.so (SONAME libamdhip64.so.7) must be the one HIP runtime
     # of the process, so that torch's streams / allocations are valid in our launches.
     import torch  # noqa: F401
 
-    path = lib_path()
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: the HIP extension is not built. Run `python -m rl_rocket_6dof_amd.build` "
             "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path)   # RTLD_LOCAL: several builds can coexist in one process (A/B benchmarking)
     u64, i64, vp = C.c_uint64, C.c_int64, C.c_void_p
     lib.r6_abi_version.restype = C.c_int
     lib.r6_params_size.restype = C.c_size_t
@@ -55,7 +55,7 @@ def load():
         raise ImportError(f"libr6dof.so ABI {lib.r6_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     if lib.r6_params_size() != C.sizeof(R6Params) or lib.r6_buffers_size() != C.sizeof(R6Buffers):
         raise ImportError("R6Params/R6Buffers layout mismatch between params.py and libr6dof.so: rebuild")
-    _LIB = lib
+    _LIBS[path] = lib
     return lib
 
 

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .compat import Box
-from .params import (ACTION_DIM, BLOCK, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS, STATE_DIM,
+from .params import (ACTION_DIM, MAX_BLOCKS, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS, STATE_DIM,
                      STAT_NAMES, R6Buffers, default_env_config, make_params)
 
 TERM_NAMES_ACC = ("atarg_tracking", "thrust_penalty", "eta", "attitude_constraint", "goal_conditions",
@@ -102,10 +102,10 @@ class BatchedRocket6DOF:
                  remove_mass: bool = False, clip_reward=None, max_episode_steps: int = 0,
                  auto_reset: bool = True, seed: Optional[int] = None, env_offset: int = 0,
                  record_terms: bool = False, record_flags: bool = True, track_episodes: bool = True,
-                 numpy_io: bool = False):
+                 numpy_io: bool = False, lib_path: Optional[str] = None):
         if num_envs < 1:
             raise ValueError("num_envs must be >= 1")
-        self.lib = _lib.load()   # raises if the HIP extension is missing -- no fallback
+        self.lib = _lib.load(lib_path)   # raises if the HIP extension is missing -- no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedRocket6DOF needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU implementation in this package")
@@ -149,8 +149,7 @@ class BatchedRocket6DOF:
         self.ep_return = torch.zeros((n,), **f32) if track else None
         self.fin_return = torch.zeros((n,), **f32) if (track and auto_reset) else None
         self.fin_length = torch.zeros((n,), dtype=torch.int32, device=dev) if (track and auto_reset) else None
-        self.n_blocks = (n + BLOCK - 1) // BLOCK
-        self.stats = torch.zeros((self.n_blocks, NUM_STATS), **f32) if track else None
+        self.stats = torch.zeros((MAX_BLOCKS, NUM_STATS), **f32) if track else None
 
         self._buf = R6Buffers()
         self._fill_buffers(self._act)

@@ -56,14 +56,29 @@ struct Inertia {          // sim:42-50, frozen at the episode's initial mass m0
     float jdiff;          // Jx - Jt
 };
 
+// sin/cos of a gimbal angle.  |x| <= pi/4 (normalised action within +-2.25) takes minimax
+// polynomials (Cephes sinf/cosf kernels, < 1 ulp of float32 on that range); anything larger falls
+// back to the full-range library routine.  The branch is wave-uniform.
+__device__ __forceinline__ void sincos_gimbal(float x, float* s, float* c) {
+    if (__builtin_expect(__any(fabsf(x) > 0.78539816f), 0)) {
+        sincosf(x, s, c);
+        return;
+    }
+    const float z = x * x;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    *s = fmaf(x * z, ps, x);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    *c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+}
+
 // env:509-521 -- no clipping of the normalised action
 __device__ __forceinline__ Control make_control_normalised(const R6Params& p, float a0, float a1, float a2) {
     const float dy = a0 * p.max_gimbal;
     const float dz = a1 * p.max_gimbal;
     const float thr = (a2 + 1.0f) * 0.5f * p.max_thrust;
     float sy, cy, sz, cz;
-    sincosf(dy, &sy, &cy);
-    sincosf(dz, &sz, &cz);
+    sincos_gimbal(dy, &sy, &cy);
+    sincos_gimbal(dz, &sz, &cz);
     Control c;
     c.tbx = thr * (cy * cz);
     c.tby = thr * (sy * cz);
@@ -130,8 +145,8 @@ __device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
     return R;
 }
 
-// sim:106-143 -- derivative of the 13 dynamic components at mass `mass`.
-__device__ __forceinline__ void rhs13(const float (&y)[kDyn], float mass, const Control& c, const Inertia& J,
+// sim:106-143 -- derivative of the 13 dynamic components; `im` = 1 / mass at this time.
+__device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Control& c, const Inertia& J,
                                       float (&dy)[kDyn]) {
     const float vx = y[3], vy = y[4], vz = y[5];
     const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
@@ -148,7 +163,6 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float mass, const 
     const float fx = fmaf(R.r00, c.tbx, fmaf(R.r01, c.tby, fmaf(R.r02, c.tbz, ca * vx)));
     const float fy = fmaf(R.r10, c.tbx, fmaf(R.r11, c.tby, fmaf(R.r12, c.tbz, ca * vy)));
     const float fz = fmaf(R.r20, c.tbx, fmaf(R.r21, c.tby, fmaf(R.r22, c.tbz, ca * vz)));
-    const float im = frcp(mass);
     dy[0] = vx;
     dy[1] = vy;
     dy[2] = vz;
@@ -176,38 +190,36 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float mass, const 
 template <int INTEG>
 __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, const Control& c, const Inertia& J,
                                          float h, float (&y1)[kDyn]) {
-    float k[kDyn];
     if constexpr (INTEG == R6_EULER) {
-        rhs13(y0, mass, c, J, k);
+        float k[kDyn];
+        rhs13(y0, frcp(mass), c, J, k);
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h, k[i], y0[i]);
     } else {
-        float acc[kDyn], yt[kDyn];
+        // Classical RK4 as a rolled loop over the four stages (one copy of the RHS in the instruction
+        // stream, register footprint of a single stage):  y1 accumulates y0 + h/6 (k1 + 2k2 + 2k3 + k4),
+        // yt is the stage argument.  Mass is linear in time: stage masses m, m-h/2 mdot (x2), m-h mdot.
         const float hh = 0.5f * h;
-        const float m_half = fmaf(-c.mdot, hh, mass);
-        const float m_full = fmaf(-c.mdot, h, mass);
-        rhs13(y0, mass, c, J, k);
-#pragma unroll
-        for (int i = 0; i < kDyn; ++i) {
-            acc[i] = k[i];
-            yt[i] = fmaf(hh, k[i], y0[i]);
-        }
-        rhs13(yt, m_half, c, J, k);
-#pragma unroll
-        for (int i = 0; i < kDyn; ++i) {
-            acc[i] = fmaf(2.0f, k[i], acc[i]);
-            yt[i] = fmaf(hh, k[i], y0[i]);
-        }
-        rhs13(yt, m_half, c, J, k);
-#pragma unroll
-        for (int i = 0; i < kDyn; ++i) {
-            acc[i] = fmaf(2.0f, k[i], acc[i]);
-            yt[i] = fmaf(h, k[i], y0[i]);
-        }
-        rhs13(yt, m_full, c, J, k);
         const float h6 = h * (1.0f / 6.0f);
+        float yt[kDyn];
 #pragma unroll
-        for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h6, acc[i] + k[i], y0[i]);
+        for (int i = 0; i < kDyn; ++i) {
+            yt[i] = y0[i];
+            y1[i] = y0[i];
+        }
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const float tm = (s == 0) ? 0.0f : ((s == 3) ? h : hh);      // stage time offset
+            const float w = (s == 0 || s == 3) ? h6 : 2.0f * h6;         // quadrature weight * h
+            const float an = (s == 2) ? h : hh;                          // next stage's step
+            float k[kDyn];
+            rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, k);
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                y1[i] = fmaf(w, k[i], y1[i]);
+                yt[i] = fmaf(an, k[i], y0[i]);
+            }
+        }
     }
 }
 
@@ -216,29 +228,40 @@ __device__ __forceinline__ bool crossing(float x_old, float x_new) {
     return (x_old <= 0.0f && x_new >= 0.0f) || (x_old >= 0.0f && x_new <= 0.0f);
 }
 
-// theta in [0,1] with H(theta) = 0, H the cubic Hermite through (0,x0,d0), (1,x1,d1), d = h*vx.
-// Safeguarded Newton, fixed 8 iterations (same procedure as oracle/oracle_np.py hermite_root).
-__device__ __forceinline__ float hermite_root(float x0, float x1, float d0, float d1) {
+// theta in [0,1] with P(theta) = 0, P = sum c[k] t^k, P(0) = x0, P(1) = x1 of opposite (or zero)
+// sign.  Safeguarded Newton from the secant point, at most 8 iterations -- the same procedure, step
+// for step, as oracle/oracle_np.py poly_root01.
+template <int N>
+__device__ __forceinline__ float poly_root01(const float (&c)[N], float x0, float x1) {
     if (x0 == 0.0f) return 0.0f;
     if (x1 == 0.0f) return 1.0f;
-    const float c3 = 2.0f * x0 - 2.0f * x1 + d0 + d1;
-    const float c2 = -3.0f * x0 + 3.0f * x1 - 2.0f * d0 - d1;
     float lo = 0.0f, hi = 1.0f;
     float th = x0 / (x0 - x1);
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
-        const float f = fmaf(fmaf(fmaf(c3, th, c2), th, d0), th, x0);
+        float f = c[N - 1], df = 0.0f;
+#pragma unroll
+        for (int k = N - 2; k >= 0; --k) {
+            df = fmaf(df, th, f);
+            f = fmaf(f, th, c[k]);
+        }
         if (f == 0.0f) break;
         if ((f > 0.0f) == (x0 > 0.0f)) lo = th; else hi = th;
-        const float df = fmaf(fmaf(3.0f * c3, th, 2.0f * c2), th, d0);
         float nt = (df != 0.0f) ? th - f / df : 0.5f * (lo + hi);
-        if (!(nt > lo && nt < hi)) nt = 0.5f * (lo + hi);
+        if (!(nt >= lo && nt <= hi)) nt = 0.5f * (lo + hi);
+        if (nt == th) break;  // converged to working precision
         th = nt;
     }
     return th;
 }
 
 // One env step of the simulator (sim:69-104) with fixed sub-steps.  Returns status (1 = ground).
+//
+// Ground event (oracle_np.event_step_rk4): theta = root of the cubic Hermite interpolant of x over
+// the sub-step, then the SAME step map is applied again with the step shortened to theta*h -- a
+// second trip through one loop body, executed only by waves that hold a crossing lane, so the event
+// costs no registers and no second copy of the integrator.  A final Newton correction in time
+// (positions only) puts the state on x = 0.
 template <int INTEG>
 __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J,
                                          float dt, int nsub) {
@@ -246,25 +269,44 @@ __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Co
     int status = 0;
 #pragma unroll 1
     for (int s = 0; s < nsub; ++s) {
-        if (status == 0) {
-            float y1[kDyn];
-            step_map<INTEG>(y, mass, c, J, h, y1);
-            float hs = h;
-            if (crossing(y[0], y1[0])) {
-                float th;
+        if (status != 0) continue;
+        float y1[kDyn];
+        float hs = h;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            step_map<INTEG>(y, mass, c, J, hs, y1);
+            if (pass == 1) {
                 if constexpr (INTEG == R6_RK4) {
-                    th = hermite_root(y[0], y1[0], h * y[3], h * y1[3]);
-                } else {
-                    th = (y[0] == 0.0f) ? 0.0f : y[0] / (y[0] - y1[0]);
+                    const float delta = -y1[0] / y1[3];
+                    if (y1[3] != 0.0f && fabsf(delta) <= h) {
+                        y1[0] = fmaf(y1[3], delta, y1[0]);
+                        y1[1] = fmaf(y1[4], delta, y1[1]);
+                        y1[2] = fmaf(y1[5], delta, y1[2]);
+                    }
                 }
-                hs = th * h;
-                step_map<INTEG>(y, mass, c, J, hs, y1);
-                status = 1;
+                break;
             }
+            if (!crossing(y[0], y1[0])) break;
+            status = 1;
+            float th;
+            if constexpr (INTEG == R6_RK4) {
+                const float d0 = h * y[3], d1 = h * y1[3];
+                const float D = (y1[0] - y[0]) - d0;
+                const float E = d1 - d0;
+                const float cc[4] = {y[0], d0, 3.0f * D - E, -2.0f * D + E};
+                th = poly_root01(cc, y[0], y1[0]);
+                hs = th * h;      // second pass: re-apply the map with the shortened step
+            } else {              // the Euler map is linear in h: interpolate, no second pass
+                th = (y[0] == 0.0f) ? 0.0f : y[0] / (y[0] - y1[0]);
 #pragma unroll
-            for (int i = 0; i < kDyn; ++i) y[i] = y1[i];
-            mass = fmaf(-c.mdot, hs, mass);
+                for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(th, y1[i] - y[i], y[i]);
+                hs = th * h;
+                break;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) y[i] = y1[i];
+        mass = fmaf(-c.mdot, hs, mass);
     }
     // sim:97, :153-154 -- quaternion renormalised after the step
     const float n2 = fmaf(y[6], y[6], fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
@@ -281,43 +323,70 @@ __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Co
 // env:528-546 -- t_go = largest positive real root of  g^2 t^4 + c2 t^2 + c1 t + c0,
 // c2 = -4|v|^2 <= 0, c1 = -24 r.v, c0 = -36|r|^2 <= 0.  (np.roots order + "first positive real"
 // selects the largest positive real root: 38k multi-root cases checked in the build container and
-// golden G5.)  Structure: p is convex for t > ti = sqrt(-c2/(6 g^2)) and concave on [0, ti].
-//   * Newton from an upper bound walks down the convex branch monotonically to the largest root;
-//   * if it runs out of the convex branch with p > 0 (no root there) the root is the single
-//     crossing of the concave branch, reached monotonically by Newton from t = 0 (p(0) = c0 < 0).
-// fp32 iterations, then one Newton correction with the residual evaluated in fp64.
+// golden G5.)  With the monic coefficients b2, b1, b0:  p is convex for t > ti = sqrt(-b2/6) and
+// concave on [0, ti], p(0) = b0 < 0.  The branch that holds the largest root is decided up front
+// from p(ti), p'(ti):
+//   * p(ti) <= 0, or p'(ti) < 0:  look on the convex branch.  Newton from a point right of every
+//     root -- tq = largest root of the bi-quadratic t^4 + b2 t^2 + b0 when b1 >= 0 (p(tq) = b1 tq >= 0),
+//     a Fujiwara bound when b1 < 0 -- descends monotonically to the largest root;
+//   * p(ti) > 0 and p'(ti) >= 0:  no root right of ti; the single crossing of the concave branch is
+//     reached monotonically by Newton from t = 0.
+// Only when p(ti) > 0 > p'(ti) and the convex branch turns out to hold no root (it has a positive
+// minimum) does the iteration restart from 0 (0.1 % of states).  Eight unrolled, branch-free Newton
+// steps cover 99 % of the lanes; a wave-uniform tail loop finishes the rest.  fp32 iterations, then
+// one Newton correction with the residual evaluated in fp64.
+struct Quartic {
+    float b2, b1, b0, ti;
+};
+
+__device__ __forceinline__ void quartic_newton(const Quartic& q, float& t, bool& left, bool& conv, bool allow_restart) {
+    const float t2 = t * t;
+    const float p = fmaf(fmaf(t2 + q.b2, t, q.b1), t, q.b0);
+    const float dp = fmaf(fmaf(4.0f, t2, 2.0f * q.b2), t, q.b1);
+    if (allow_restart && !left && p > 0.0f && (dp <= 0.0f || t < q.ti)) {
+        left = true;  // fell off the convex branch without meeting a root: restart on the concave one
+        t = 0.0f;
+        conv = false;
+        return;
+    }
+    left = left || (p <= 0.0f);                      // at / left of the root: finish from the left
+    const float step = (dp > 0.0f) ? p * frcp(dp) : 0.0f;
+    float tn = t - step;
+    tn = left ? fmaxf(tn, t) : fminf(tn, t);          // monotone (guards round-off)
+    conv = fabsf(tn - t) <= 2e-7f * fabsf(tn);
+    t = tn;
+}
+
 __device__ __forceinline__ float t_go_quartic(float c2, float c1, float c0) {
     constexpr float g2 = (float)(kGShaping * kGShaping);
     constexpr float ig2 = (float)(1.0 / (kGShaping * kGShaping));
-    const float b2 = c2 * ig2, b1 = c1 * ig2, b0 = c0 * ig2;  // monic
-    // Fujiwara bound on every root modulus: 2 max(|b2|^(1/2), |b1|^(1/3), |b0/2|^(1/4))
-    const float m2 = fsqrt(fabsf(b2));
-    const float m1 = fexp2(flog2(fmaxf(fabsf(b1), 1e-30f)) * (1.0f / 3.0f));
-    const float m0 = fsqrt(fsqrt(0.5f * fabsf(b0)));
-    const float ti = fsqrt(fabsf(b2) * (1.0f / 6.0f));
-    float t = 2.002f * fmaxf(m2, fmaxf(m1, m0)) + 1e-6f;
-    bool left = false;  // false: descending the convex branch; true: ascending the concave one
+    Quartic q;
+    q.b2 = c2 * ig2;
+    q.b1 = c1 * ig2;
+    q.b0 = c0 * ig2;
+    const float ti2 = q.b2 * (-1.0f / 6.0f);
+    q.ti = fsqrt(ti2);
+    const float p_i = fmaf(-5.0f * ti2, ti2, fmaf(q.b1, q.ti, q.b0));   // p(ti), using b2 = -6 ti^2
+    const float dp_i = fmaf(-8.0f * ti2, q.ti, q.b1);                   // p'(ti)
+    bool left = (p_i > 0.0f) && (dp_i >= 0.0f);
+    const bool may_restart = (p_i > 0.0f) && (dp_i < 0.0f);
+    float t;
+    {
+        const float tq = fsqrt(0.5f * (fsqrt(fmaf(q.b2, q.b2, -4.0f * q.b0)) - q.b2));
+        const float m1 = fexp2(flog2(fmaxf(fabsf(q.b1), 1e-30f)) * (1.0f / 3.0f));
+        const float fuji = 2.002f * fmaxf(fsqrt(fabsf(q.b2)), fmaxf(m1, fsqrt(fsqrt(0.5f * fabsf(q.b0))))) + 1e-6f;
+        t = left ? 0.0f : ((q.b1 >= 0.0f) ? tq : fuji);
+    }
+    bool conv = false;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) quartic_newton(q, t, left, conv, false);
+    if (__builtin_expect(__any(!conv || may_restart), 0)) {
+        // tail: slow lanes, and the rare lanes that may have to restart on the concave branch
 #pragma unroll 1
-    for (int it = 0; it < 24; ++it) {
-        const float t2 = t * t;
-        const float p = fmaf(fmaf(t2 + b2, t, b1), t, b0);
-        const float dp = fmaf(fmaf(4.0f, t2, 2.0f * b2), t, b1);
-        if (!left) {
-            if (p <= 0.0f) {
-                left = true;  // at / just left of the root: finish monotonically from the left
-            } else if (dp <= 0.0f || t < ti) {
-                left = true;  // p > 0 but off the convex branch: no root there, restart at t = 0
-                t = 0.0f;
-                continue;
-            }
+        for (int it = 0; it < 24; ++it) {
+            quartic_newton(q, t, left, conv, may_restart);
+            if (__all(conv)) break;
         }
-        float tn = t - p * frcp(dp);
-        if (left) tn = fmaxf(tn, t);           // monotone from the left (guards round-off)
-        else tn = fminf(tn, t);                // monotone from the right
-        if (!(tn >= 0.0f)) tn = 0.0f;
-        const bool conv = fabsf(tn - t) <= 2e-7f * fabsf(tn);
-        t = tn;
-        if (__all(conv)) break;
     }
     // fp64 polish on the un-normalised polynomial (coefficients as the reference hands them to
     // np.roots: float32 values promoted to float64)
@@ -362,7 +431,7 @@ __device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[
         const float im = frcp(mass);
         const float lim = p.max_thrust * im;                      // env:562
         if (!(an <= lim)) {
-            const float sc = lim / an;
+            const float sc = lim * frcp(an);
             ax *= sc;
             ay *= sc;
             az *= sc;

@@ -7,8 +7,12 @@
 // memory only ever sees contiguous 16 B-per-lane accesses.  No MFMA: there is no contraction here.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
+#include <cstddef>
 #include <cstring>
+#include <type_traits>
 
 #include "r6_device.hpp"
 
@@ -16,199 +20,69 @@ namespace r6 {
 
 constexpr int kBlock = R6_BLOCK;
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+typedef float f4 __attribute__((ext_vector_type(4)));  // plain vector type: usable in any address space
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 
 // -------------------------------------------------------------------------------------------------
 // Rocket6DOF.step (env:201-231) for one shard.
+//
+// Wave-autonomous tiles: the grid is sized to the resident capacity of the chip and every wave64
+// walks over 64-env tiles (tile = wave_gid + k * total_waves).  There is no workgroup barrier inside
+// the tile loop -- each wave owns a private LDS tile for the AoS observation edge -- so the waves of
+// a CU drift apart and their load / compute / store phases overlap.  The hot loop is kept lean so
+// that many waves are resident (occupancy is what hides HBM latency here):
+//   * ground events re-enter the same integrator loop body (no second copy, no extra registers);
+//   * finished episodes are not re-sampled in the divergent per-lane path: their env indices go to a
+//     per-workgroup LDS queue that is drained densely (all 256 lanes busy) once, after the loop;
+//   * kernel parameters are re-read from the kernarg segment per phase instead of living in ~110
+//     SGPRs across the loop.
 // -------------------------------------------------------------------------------------------------
-template <int INTEG, int SHAPING, int OD>
-__global__ __launch_bounds__(kBlock) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
-                                                      const uint64_t step_index, const uint64_t env_offset) {
-    __shared__ __attribute__((aligned(16))) float tile[kBlock * OD];
-    __shared__ float wave_stats[kBlock / 64][R6_NUM_STATS];
+constexpr int kWaves = kBlock / 64;
+constexpr int kResetQueueCap = 2048;
 
-    const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kBlock;
-    const int64_t i = base + tid;
-    const int64_t ld = b.ld;
-    const int64_t rem = b.n - base;
-    const int nblk = rem < kBlock ? (int)rem : kBlock;  // live envs in this workgroup
-    const bool live = tid < nblk;
-
-    // ---- actions: AoS (n,3) -> LDS, 16 B per lane ------------------------------------------------
-    {
-        const float* src = b.action + base * R6_ACTION_DIM;
-        if (nblk == kBlock) {
-            if (tid < kBlock * R6_ACTION_DIM / 4) st4(&tile[4 * tid], ld4(src + 4 * tid));
-        } else {
-            for (int k = tid; k < nblk * R6_ACTION_DIM; k += kBlock) tile[k] = src[k];
-        }
-    }
-
-    // ---- state: SoA rows, coalesced ---------------------------------------------------------------
-    float y[kDyn];
-    float mass, m0, v0 = 0.0f;
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < kDyn; ++j) y[j] = b.state[j * ld + i];
-        mass = b.state[13 * ld + i];
-        m0 = b.epconst[i];
-        if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = b.epconst[ld + i];
-    } else {  // benign padding lane
-#pragma unroll
-        for (int j = 0; j < kDyn; ++j) y[j] = 0.0f;
-        y[0] = 1000.0f;
-        y[6] = 1.0f;
-        mass = m0 = 4.0e4f;
-    }
-    uint32_t ep_step = 0;
-    float ep_ret = 0.0f;
-    if (live && b.ep_step) ep_step = b.ep_step[i];
-    if (live && b.ep_return) ep_ret = b.ep_return[i];
-
-    __syncthreads();
-    float a0 = 0.0f, a1 = 0.0f, a2 = -1.0f;
-    if (live) {
-        a0 = tile[3 * tid + 0];
-        a1 = tile[3 * tid + 1];
-        a2 = tile[3 * tid + 2];
-    }
-    __syncthreads();  // tile is reused for the observations below
-
-    // ---- dynamics (sim:69-143) --------------------------------------------------------------------
-    const Control c = make_control_normalised(p, a0, a1, a2);
-    const Inertia J = make_inertia(m0);
-    const int status = integrate<INTEG>(y, mass, c, J, p.dt, p.n_substeps);
-
-    // ---- termination (env:213, :591-593) ------------------------------------------------------------
-    const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
-    bool done = (status != 0) || bnd;
-
-    // ---- reward (env:215, :228-229, :317-402) -------------------------------------------------------
-    const RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
-    float rew = rw.sum + (bnd ? p.bounds_penalty : 0.0f);
-    if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);  // main_6DOF.py:33-42
-
-    // ---- fused TimeLimit / Monitor (main_6DOF.py:47-51) ---------------------------------------------
-    ep_step += 1u;
-    ep_ret += rew;
-    bool truncated = false;
-    if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
-        truncated = !done;
-        done = true;
-    }
-
-    float obs[R6_STATE_DIM];
-#pragma unroll
-    for (int j = 0; j < kDyn; ++j) obs[j] = y[j] * p.inv_norm[j];
-    obs[13] = mass * p.inv_norm[13];
-
-    if (live) {
-        b.reward[i] = rew;
-        b.done[i] = done ? 1 : 0;
-        if (b.flags)
-            b.flags[i] = (uint8_t)((status ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
-                                   (truncated ? R6_FLAG_TRUNCATED : 0));
-        if (b.terms) {
-#pragma unroll
-            for (int t = 0; t < R6_NUM_TERMS; ++t) b.terms[t * ld + i] = rw.terms[t];
-        }
-    }
-
-    // ---- per-workgroup episode statistics (deterministic tree sums, no atomics) -------------------------
-    if (b.stats) {
-        const bool fin = live && done;
-        if (__any(fin)) {
-            float sv[R6_NUM_STATS];
-            sv[R6_STAT_EPISODES] = fin ? 1.0f : 0.0f;
-            sv[R6_STAT_RETURN] = fin ? ep_ret : 0.0f;
-            sv[R6_STAT_RETURN_SQ] = fin ? ep_ret * ep_ret : 0.0f;
-            sv[R6_STAT_LENGTH] = fin ? (float)ep_step : 0.0f;
-            sv[R6_STAT_GROUND] = (fin && status) ? 1.0f : 0.0f;
-            sv[R6_STAT_BOUNDS] = (fin && bnd) ? 1.0f : 0.0f;
-            sv[R6_STAT_TRUNCATED] = (fin && truncated) ? 1.0f : 0.0f;
-            sv[R6_STAT_LANDED] = (fin && rw.landed) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int k = 0; k < R6_NUM_STATS; ++k) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sv[k] += __shfl_xor(sv[k], o, 64);
-            }
-            if ((tid & 63) == 0) {
-#pragma unroll
-                for (int k = 0; k < R6_NUM_STATS; ++k) wave_stats[tid >> 6][k] = sv[k];
-            }
-        } else if ((tid & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < R6_NUM_STATS; ++k) wave_stats[tid >> 6][k] = 0.0f;
-        }
-    }
-
-    // ---- in-kernel auto-reset (VecEnv semantics: obs of the NEW episode is returned, the terminal
-    //      observation goes to final_obs) ------------------------------------------------------------
-    if (live && done && p.auto_reset) {
-        if (b.final_obs) {
-#pragma unroll
-            for (int j = 0; j < OD; ++j) b.final_obs[i * OD + j] = obs[j];
-        }
-        if (b.fin_return) b.fin_return[i] = ep_ret;
-        if (b.fin_length) b.fin_length[i] = ep_step;
-        float ic[R6_STATE_DIM];
-        sample_ic(p, seed, env_offset + (uint64_t)i, step_index, ic);
-#pragma unroll
-        for (int j = 0; j < kDyn; ++j) y[j] = ic[j];
-        mass = ic[13];
-        b.epconst[i] = ic[13];
-        b.epconst[ld + i] = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
-#pragma unroll
-        for (int j = 0; j < R6_STATE_DIM; ++j) obs[j] = ic[j] * p.inv_norm[j];
-        ep_step = 0u;
-        ep_ret = 0.0f;
-    }
-
-    // ---- write back state (SoA) ----------------------------------------------------------------------
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < kDyn; ++j) b.state[j * ld + i] = y[j];
-        b.state[13 * ld + i] = mass;
-        if (b.ep_step) b.ep_step[i] = ep_step;
-        if (b.ep_return) b.ep_return[i] = ep_ret;
-    }
-
-    // ---- observations: registers -> LDS (row-major tile) -> 16 B-per-lane contiguous stores ---------
-#pragma unroll
-    for (int j = 0; j < OD; ++j) tile[tid * OD + j] = obs[j];
-    __syncthreads();
-    if (b.stats && tid < R6_NUM_STATS) {
-        const float add = (wave_stats[0][tid] + wave_stats[1][tid]) + (wave_stats[2][tid] + wave_stats[3][tid]);
-        const float cnt = (wave_stats[0][0] + wave_stats[1][0]) + (wave_stats[2][0] + wave_stats[3][0]);
-        if (cnt > 0.0f) b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += add;
-    }
-    {
-        float* dst = b.obs + base * OD;
-        if (nblk == kBlock) {
-            constexpr int n4 = kBlock * OD / 4;
-#pragma unroll
-            for (int k = 0; k < (n4 + kBlock - 1) / kBlock; ++k) {
-                const int q = tid + k * kBlock;
-                if (q < n4) st4(dst + 4 * q, ld4(&tile[4 * q]));
-            }
-        } else {
-            for (int k = tid; k < nblk * OD; k += kBlock) dst[k] = tile[k];
-        }
-    }
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS instructions of one wave execute in order; this only stops the compiler from moving
+    // LDS accesses across the point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// -------------------------------------------------------------------------------------------------
-// Rocket6DOF.reset (env:180-199) for masked envs.
-// -------------------------------------------------------------------------------------------------
+// A wave-uniform pointer made opaque to the optimiser: keeps `base + lane` from being folded into
+// one divergent 64-bit index, so accesses are selected as  global_* v, v_lane_offset, s[base]  --
+// one VGPR of addressing for all rows instead of a 64-bit VGPR pair per row.
+template <typename T>
+using gptr = __attribute__((address_space(1))) T*;
+
+template <typename T>
+__device__ __forceinline__ gptr<T> uniform_ptr(T* p) {
+    asm volatile("" : "+s"(p));
+    return (gptr<T>)p;  // global address space: selected as global_* with an SGPR base
+}
+
+// The kernel parameters live in the kernarg segment.  Reading them through a pointer that is
+// re-laundered per phase of the tile loop makes the compiler issue the scalar loads where the
+// values are used (a handful of s_load_dwordxN per phase, scalar-cache hits) instead of hoisting all
+// ~110 parameter dwords out of the loop and spilling SGPRs.  R6Params is kernel argument 0,
+// R6Buffers kernel argument 1 right behind it (both are 8-byte multiples).
+typedef const __attribute__((address_space(4))) char* kernarg_ptr_t;
+static_assert(sizeof(R6Params) % 8 == 0, "R6Buffers must follow R6Params without padding");
+__device__ __forceinline__ R6Params load_params() {
+    kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const R6Params*)k;
+}
+__device__ __forceinline__ R6Buffers load_buffers() {
+    kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const R6Buffers*)(k + sizeof(R6Params));
+}
+
+// env:180-199 for one env, written straight to HBM (used by the dense drain of the reset queue).
 template <int OD>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const R6Params p, const R6Buffers b, const uint8_t* mask,
-                                                       const uint64_t seed, const uint64_t step_index,
-                                                       const uint64_t env_offset) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= b.n) return;
-    if (mask && !mask[i]) return;
+__device__ __forceinline__ void reset_env_global(const R6Params& p, const R6Buffers& b, int64_t i, uint64_t seed,
+                                                 uint64_t step_index, uint64_t env_offset) {
     const int64_t ld = b.ld;
     float ic[R6_STATE_DIM];
     sample_ic(p, seed, env_offset + (uint64_t)i, step_index, ic);
@@ -222,6 +96,272 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const R6Params p, const R
     }
     if (b.ep_step) b.ep_step[i] = 0u;
     if (b.ep_return) b.ep_return[i] = 0.0f;
+}
+
+// Inputs of one 64-env tile, one lane = one env.  Loading is split from processing so that the tile
+// loop can issue the NEXT tile's loads before it computes the current one (software pipelining in
+// registers: every resident wave keeps ~4.6 KB of HBM reads in flight while its VALU work runs).
+struct TileIn {
+    float y[kDyn];
+    float mass, m0, v0, a0, a1, a2, ep_ret;
+    uint32_t ep_step;
+};
+
+template <int SHAPING, bool FULL>
+__device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64_t e0, int lane, TileIn& in) {
+    const int64_t ld = b.ld;
+    const bool live = FULL ? true : (lane < b.n - e0);
+    in.mass = in.m0 = 4.0e4f;
+    in.v0 = in.a0 = in.a1 = in.ep_ret = 0.0f;
+    in.a2 = -1.0f;
+    in.ep_step = 0u;
+#pragma unroll
+    for (int j = 0; j < kDyn; ++j) in.y[j] = (j == 0) ? 1000.0f : ((j == 6) ? 1.0f : 0.0f);  // benign padding lane
+    if (live) {
+        const float* row = b.state + e0;   // SoA rows: coalesced 256 B per row; the row pointer advances in SALU
+#pragma unroll
+        for (int j = 0; j < kDyn; ++j) {
+            in.y[j] = uniform_ptr(row)[lane];
+            row += ld;
+        }
+        in.mass = uniform_ptr(row)[lane];
+        in.m0 = uniform_ptr(b.epconst + e0)[lane];
+        if constexpr (SHAPING == R6_SHAPING_VELOCITY) in.v0 = uniform_ptr(b.epconst + (ld + e0))[lane];
+        if (has_ep) {
+            in.ep_step = uniform_ptr(b.ep_step + e0)[lane];
+            in.ep_ret = uniform_ptr(b.ep_return + e0)[lane];
+        }
+        const gptr<const float> act = uniform_ptr(b.action + e0 * R6_ACTION_DIM);
+        in.a0 = act[3 * lane + 0];  // 3 x 4 B at a 12 B lane stride: the wave touches the same 768 B
+        in.a1 = act[3 * lane + 1];  // three times, the repeats are L1 hits
+        in.a2 = act[3 * lane + 2];
+    }
+}
+
+template <int INTEG, int SHAPING, int OD>
+__global__ __launch_bounds__(kBlock) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
+                                                      const uint64_t step_index, const uint64_t env_offset) {
+    // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
+    // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
+    // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
+    // reset distribution, the RNG keys) is re-read from the kernarg segment inside those paths
+    // (load_params / load_buffers), so that neither occupies SGPRs across the loop.
+    __shared__ __attribute__((aligned(16))) float tiles[kWaves][64 * OD];
+    __shared__ float lds_inv_norm[R6_STATE_DIM];
+    __shared__ int rq[kResetQueueCap];
+    __shared__ int rq_count;
+    __shared__ float blk_stats[R6_NUM_STATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar tile arithmetic
+    float* tile = tiles[wave];
+    const int64_t n = b.n;
+    const int64_t ld = b.ld;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * kWaves;
+    const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
+    const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
+
+    if (tid == 0) rq_count = 0;
+    if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
+    if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
+        const kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        lds_inv_norm[tid] = ((const __attribute__((address_space(4))) float*)(k + offsetof(R6Params, inv_norm)))[tid];
+    }
+    __syncthreads();
+
+    // One 64-env tile.  FULL = all 64 lanes are live (every tile but possibly the last one).
+    auto process_tile = [&](const int64_t e0, const TileIn& in, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int64_t rem = n - e0;  // envs from the tile's start to the end of the shard (> 0)
+        const bool live = FULL ? true : (lane < rem);
+        float y[kDyn];
+#pragma unroll
+        for (int j = 0; j < kDyn; ++j) y[j] = in.y[j];
+        float mass = in.mass, ep_ret = in.ep_ret;
+        const float m0 = in.m0, v0 = in.v0, a0 = in.a0, a1 = in.a1, a2 = in.a2;
+        uint32_t ep_step = in.ep_step;
+
+        // ---- dynamics (sim:69-143) -----------------------------------------------------------------
+        const Control c = make_control_normalised(p, a0, a1, a2);
+        const Inertia J = make_inertia(m0);
+#ifdef R6_ABLATE_INTEG   // timing-only build: dynamics skipped, inputs kept live
+        int status = 0;
+        asm volatile("" :: "v"(c.tbx), "v"(c.tby), "v"(c.tbz), "v"(J.inv_jt), "v"(J.jdiff));
+        y[3] += p.dt * c.mdot;
+#else
+        const int status = integrate<INTEG>(y, mass, c, J, p.dt, p.n_substeps);
+#endif
+
+        // ---- termination (env:213, :591-593), reward (env:215, :228-229, :317-402),
+        //      fused ClipReward / TimeLimit / Monitor (main_6DOF.py:33-51) ----------------------------
+        const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
+        bool done = (status != 0) || bnd;
+#ifdef R6_ABLATE_REWARD  // timing-only build: reward skipped
+        RewardOut rw;
+        for (int k = 0; k < R6_NUM_TERMS; ++k) rw.terms[k] = 0.0f;
+        rw.sum = y[0] * p.alfa + c.thrust * p.beta + mass + v0;
+        rw.landed = false;
+#else
+        const RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
+#endif
+        float rew = rw.sum + (bnd ? p.bounds_penalty : 0.0f);
+        if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
+        ep_step += 1u;
+        ep_ret += rew;
+        bool truncated = false;
+        if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
+            truncated = !done;
+            done = true;
+        }
+
+        // ---- outputs: reward, done, state rows, counters -----------------------------------------------
+        if (live) {
+            uniform_ptr(b.reward + e0)[lane] = rew;
+            uniform_ptr(b.done + e0)[lane] = done ? 1 : 0;
+            if (b.flags)
+                uniform_ptr(b.flags + e0)[lane] = (uint8_t)((status ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
+                                                            (truncated ? R6_FLAG_TRUNCATED : 0));
+            float* row = b.state + e0;
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) {
+                uniform_ptr(row)[lane] = y[j];
+                row += ld;
+            }
+            uniform_ptr(row)[lane] = mass;
+            if (has_ep) {
+                uniform_ptr(b.ep_step + e0)[lane] = ep_step;
+                uniform_ptr(b.ep_return + e0)[lane] = ep_ret;
+            }
+            if (b.terms) {
+                float* trow = b.terms + e0;
+#pragma unroll
+                for (int k = 0; k < R6_NUM_TERMS; ++k) {
+                    uniform_ptr(trow)[lane] = rw.terms[k];
+                    trow += ld;
+                }
+            }
+        }
+
+        // ---- observation (env:503-504): registers -> LDS row-major tile ---------------------------------
+#pragma unroll
+        for (int j = 0; j < kDyn; ++j) {
+            if (j < OD) tile[lane * OD + j] = y[j] * lds_inv_norm[j];
+        }
+        if (OD == 14) tile[lane * OD + (OD - 1)] = mass * lds_inv_norm[13];
+
+        // ---- finished episodes: terminal outputs now; the re-sampling (env:180-199) is deferred to
+        //      the dense drain after the loop, which overwrites state / obs / counters of these envs ---
+        if (live && done) {
+            const R6Buffers bb = load_buffers();
+            if (bb.stats) {
+                atomicAdd(&blk_stats[R6_STAT_EPISODES], 1.0f);
+                atomicAdd(&blk_stats[R6_STAT_RETURN], ep_ret);
+                atomicAdd(&blk_stats[R6_STAT_RETURN_SQ], ep_ret * ep_ret);
+                atomicAdd(&blk_stats[R6_STAT_LENGTH], (float)ep_step);
+                if (status) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
+                if (bnd) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
+                if (truncated) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
+                if (rw.landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
+            }
+            if (p.auto_reset) {
+                const int64_t i = e0 + lane;
+                if (bb.final_obs) {
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = tile[lane * OD + j];
+                }
+                if (bb.fin_return) bb.fin_return[i] = ep_ret;
+                if (bb.fin_length) bb.fin_length[i] = ep_step;
+                const int slot = atomicAdd(&rq_count, 1);
+                if (slot < kResetQueueCap) rq[slot] = (int)i;  // overflow: found again by the drain's scan
+            }
+        }
+
+        // ---- LDS tile -> contiguous 16 B-per-lane stores of the (64, OD) observation block ---------------
+        wave_lds_sync();
+        {
+            const gptr<float> dst = uniform_ptr(b.obs + e0 * OD);
+            if constexpr (FULL) {
+                constexpr int n4 = 64 * OD / 4;
+#pragma unroll
+                for (int k = 0; k < (n4 + 63) / 64; ++k) {
+                    const int q = lane + 64 * k;
+                    if (q < n4) *(gptr<f4>)(dst + 4 * q) = ld4(&tile[4 * q]);
+                }
+            } else {
+                for (int k = lane; k < (int)rem * OD; k += 64) dst[k] = tile[k];
+            }
+        }
+        wave_lds_sync();  // before the next tile overwrites the LDS tile
+    };
+
+#ifdef R6_STAGGER   // experiment: de-phase the co-resident workgroups of a CU
+    {
+        const int cls = (blockIdx.x / 256) & 3;
+        for (int k = 0; k < cls; ++k) __builtin_amdgcn_s_sleep(R6_STAGGER);
+    }
+#endif
+    // Tile loop, software-pipelined: the loads of tile k+1 are issued before tile k is computed.
+    const int64_t n_full = n >> 6;  // tiles [0, n_full) are full; tile n_full (if any) is partial
+    TileIn nxt;
+    if (t_first < n_full)
+        load_tile<SHAPING, true>(b, has_ep, t_first * 64, lane, nxt);
+    else if (t_first < n_tiles)
+        load_tile<SHAPING, false>(b, has_ep, t_first * 64, lane, nxt);
+#pragma unroll 1
+    for (int64_t t = t_first; t < n_tiles; t += nw) {
+        const TileIn cur = nxt;
+        const int64_t tn = t + nw;
+        if (tn < n_full)
+            load_tile<SHAPING, true>(b, has_ep, tn * 64, lane, nxt);
+        else if (tn < n_tiles)
+            load_tile<SHAPING, false>(b, has_ep, tn * 64, lane, nxt);
+        if (t < n_full)
+            process_tile(t * 64, cur, std::true_type{});
+        else
+            process_tile(t * 64, cur, std::false_type{});
+    }
+
+    // __syncthreads() drains every wave's outstanding stores (s_waitcnt vmcnt(0)) before the barrier,
+    // so the drain below overwrites the terminal state / obs of the finished envs in order.
+    __syncthreads();
+
+    const int n_queued = rq_count;
+    if (n_queued > 0) {
+        const R6Buffers bb = load_buffers();
+        if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
+
+        // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
+        const R6Params pp = load_params();
+        if (n_queued <= kResetQueueCap) {
+            for (int k = tid; k < n_queued; k += kBlock)
+                reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
+        } else {
+            // queue overflow (mass termination): rescan the done flags of this workgroup's tiles
+            for (int64_t tt = t_first; tt < n_tiles; tt += nw) {
+                const int64_t ii = tt * 64 + lane;
+                if (ii < bb.n && bb.done[ii]) reset_env_global<OD>(pp, bb, ii, seed, step_index, env_offset);
+            }
+        }
+    } else if (!p.auto_reset) {
+        const R6Buffers bb = load_buffers();
+        if (bb.stats && tid < R6_NUM_STATS && blk_stats[0] > 0.0f)
+            bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Rocket6DOF.reset (env:180-199) for masked envs.
+// -------------------------------------------------------------------------------------------------
+template <int OD>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const R6Params p, const R6Buffers b, const uint8_t* mask,
+                                                       const uint64_t seed, const uint64_t step_index,
+                                                       const uint64_t env_offset) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= b.n) return;
+    if (mask && !mask[i]) return;
+    reset_env_global<OD>(p, b, i, seed, step_index, env_offset);
 }
 
 template <int OD>
@@ -263,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void rhs_kernel(const float* ys, const floa
     const float mass = ys[13 * ld + i];
     const Control c = make_control_physical(u[3 * i + 0], u[3 * i + 1], u[3 * i + 2]);
     const Inertia J = make_inertia(epconst[i]);
-    rhs13(y, mass, c, J, dy);
+    rhs13(y, 1.0f / mass, c, J, dy);
 #pragma unroll
     for (int j = 0; j < kDyn; ++j) dys[j * ld + i] = dy[j];
     dys[13 * ld + i] = -c.mdot;
@@ -297,6 +437,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int validate_common(const R6Params* p, const R6Buffers* b) {
     if (!p || !b) return fail(R6_E_BADARG, "null params/buffers");
     if (b->n < 0 || b->ld < b->n) return fail(R6_E_BADARG, "need 0 <= n <= ld");
+    if (b->n >= (int64_t)1 << 31) return fail(R6_E_BADARG, "n must be < 2^31 per shard");
     if (p->obs_dim != 13 && p->obs_dim != 14) return fail(R6_E_BADARG, "obs_dim must be 13 or 14");
     if (p->integrator != R6_EULER && p->integrator != R6_RK4) return fail(R6_E_BADARG, "bad integrator");
     if (p->n_substeps < 1 || p->n_substeps > 4096) return fail(R6_E_BADARG, "n_substeps out of range");
@@ -308,12 +449,45 @@ int validate_common(const R6Params* p, const R6Buffers* b) {
 
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + r6::kBlock - 1) / r6::kBlock)); }
 
+// Resident capacity (workgroups) of the current device for one step-kernel instance, cached.
+template <typename K>
+int resident_blocks(K kernel, int slot) {
+    static std::atomic<int> cache[16][8];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int v = cache[dev][slot].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, r6::kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    v = per_cu * cus;
+    if (const char* e = std::getenv("R6_GRID_BLOCKS")) {  // tuning knob
+        const int o = std::atoi(e);
+        if (o > 0) v = o;
+    }
+    if (v > R6_MAX_BLOCKS) v = R6_MAX_BLOCKS;
+    cache[dev][slot].store(v, std::memory_order_relaxed);
+    return v;
+}
+
+template <int INTEG, int SHAPING, int OD>
+void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
+    auto kernel = r6::step_kernel<INTEG, SHAPING, OD>;
+    const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);
+    const int64_t n_tiles = (b.n + 63) / 64;
+    int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
+    const int cap = resident_blocks(kernel, slot);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
+}
+
 template <int INTEG, int SHAPING>
 void launch_step_od(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
     if (p.obs_dim == 14)
-        hipLaunchKernelGGL((r6::step_kernel<INTEG, SHAPING, 14>), grid_for(b.n), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
+        launch_step_inst<INTEG, SHAPING, 14>(p, b, seed, step, off, s);
     else
-        hipLaunchKernelGGL((r6::step_kernel<INTEG, SHAPING, 13>), grid_for(b.n), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
+        launch_step_inst<INTEG, SHAPING, 13>(p, b, seed, step, off, s);
 }
 
 }  // namespace

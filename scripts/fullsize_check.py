@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Full-size sanity (GPU box): N = 2^20, auto-reset rollout; sampled envs checked against the oracle."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import oracle_np as onp
+from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+cfg = default_env_config()
+P = onp.OracleParams.from_config(cfg)
+env = BatchedRocket6DOF(n, cfg, seed=42, record_flags=True, track_episodes=True)
+env.reset()
+g = torch.Generator(device=env.device).manual_seed(7)
+rng = np.random.RandomState(0)
+worst = 0.0; ndone = []
+for k in range(260):
+    a = torch.rand((n, 3), generator=g, device=env.device) * 2 - 1
+    check = k in (0, 50, 120, 180, 259)
+    if check:
+        idx = rng.choice(n, 96, replace=False)
+        pre = env.get_state()[idx].cpu().numpy().astype(np.float64)
+        m0 = env.epconst[0, idx].cpu().numpy()
+    obs, rew, done, _ = env.step(a)
+    ndone.append(int(done.sum().item()))
+    if check:
+        post = env.get_state()[idx].cpu().numpy()
+        act = a[idx].cpu().numpy(); r = rew[idx].cpu().numpy(); d = done[idx].cpu().numpy(); ob = obs[idx].cpu().numpy()
+        fin = env.final_obs[idx].cpu().numpy()
+        for j in range(len(idx)):
+            o = onp.env_step(pre[j], float(m0[j]), act[j], P, "rk4")
+            assert bool(d[j]) == o["done"], (k, j)
+            want_obs = o["obs"]
+            got_obs = fin[j] if d[j] else ob[j]
+            e = (np.abs(got_obs - want_obs) / np.maximum(np.abs(want_obs), 1.0)).max()
+            worst = max(worst, e)
+            assert e < 1e-5, (k, j, e, got_obs, want_obs)
+            assert abs(r[j] - o["reward"]) < 1e-5 * max(1, abs(o["reward"])), (k, j, r[j], o["reward"])
+            if not d[j]:
+                err = np.abs(post[j] - o["post"]) / np.maximum(np.abs(o["post"]), P.normalizer)
+                assert err.max() < 1e-5, (k, j, err)
+        st = env.get_state()
+        assert torch.isfinite(st).all() and torch.isfinite(obs).all()
+        qn = st[:, 6:10].norm(dim=1)
+        assert (qn - 1).abs().max() < 1e-5
+torch.cuda.synchronize()
+stats = env.episode_stats()
+print("done/step (last 10):", ndone[-10:], "total", sum(ndone), "stats", stats)
+assert abs(stats["episodes"] - sum(ndone)) < 0.5
+print(f"OK n={n}: worst obs err vs oracle {worst:.2e}")

@@ -5,7 +5,7 @@
 Tolerance (BASELINE.json north_star): per-step outputs within 1e-5 relative fp32, done masks
 bit-exact.  "Relative" is taken against max(|reference|, natural scale) where the natural scale of a
 state component is the reference's own observation normaliser (so the test is a 1e-5 bound on the
-normalised observation error), of a reward term 1e-1 (the per-step `eta` bonus), of the total reward 1.
+normalised observation error); reward-term scales are given at TERM_SCALE; the total reward's is 1.
 """
 import json
 
@@ -17,7 +17,10 @@ from conftest import assert_close_scaled, load_golden
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
-TERM_SCALE = 1e-1
+# natural magnitude of the 7 reward terms with config.yaml coefficients: tracking ~0.1, thrust
+# penalty <= 0.01, eta = 0.1 per step; attitude (gamma = -10), goal (kappa = 10), final position /
+# velocity (up to max_v_f * w_v_f = 37.5) are O(1..10) quantities whose fp32 resolution is ~1e-6.
+TERM_SCALE = np.array([1e-1, 1e-1, 1e-1, 1.0, 1.0, 1.0, 1.0])
 REWARD_SCALE = 1.0
 
 
@@ -192,6 +195,14 @@ def test_g6_fixed_step_maps(torch_cuda, cfg, P, name, integ, h):
     got = env.get_state().cpu().numpy().astype(np.float64)
     want = g6[f"single_{name}"].copy()
     want[:, 6:10] /= np.linalg.norm(want[:, 6:10], axis=1, keepdims=True)   # the kernel renormalises (simulator.py:97)
+    # the fixture applies the bare map (no event handling); the kernel localises ground crossings, so
+    # the handful of cases that cross x = 0 inside this step are checked for the event instead
+    cross = (g6["pre"][:, 0] >= 0) & (want[:, 0] <= 0)
+    assert 0 < cross.sum() < 20
+    fl = env.flags.cpu().numpy()
+    np.testing.assert_array_equal((fl & 1).astype(bool), cross)
+    assert np.abs(got[cross, 0]).max() < 1e-4
+    got, want = got[~cross], want[~cross]
     e = assert_close_scaled(got, want, P.normalizer[None, :], RTOL, f"G6 {name}")
     print(f"[G6 {name}] worst scaled err {e:.2e}")
 

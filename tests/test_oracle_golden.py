@@ -133,26 +133,31 @@ def test_g6_free_running_rollouts(P, g6, name, integ, h):
         assert_close_scaled(y, ys[len(acts)], _scale(P), 1e-7, f"rollout {name} {r}")
 
 
-def test_hermite_root_properties():
+def test_event_root_properties():
     rng = np.random.RandomState(3)
-    for _ in range(500):
-        # physically consistent sub-step: x(θ) = x0 + d0 θ + ½ a θ² + jerk-ish cubic term
-        d0 = -rng.uniform(0.1, 15)
-        a = rng.uniform(-3, 3)
-        j = rng.uniform(-0.5, 0.5)
-        th_true = rng.uniform(0.02, 0.98)
-        x0 = -(d0 * th_true + 0.5 * a * th_true ** 2 + j * th_true ** 3)
-        x1 = x0 + d0 + 0.5 * a + j
-        d1 = d0 + a + 3 * j
-        if not (x0 > 0 > x1):
-            continue
-        th = onp.hermite_root(x0, x1, d0, d1)
-        assert abs(th - th_true) < 1e-12          # a cubic is reproduced exactly by its Hermite form
-    for _ in range(500):                            # wild inputs: stays inside the bracket
-        th = onp.hermite_root(rng.uniform(0.01, 10), -rng.uniform(0.01, 10), rng.normal() * 10, rng.normal() * 10)
-        assert 0.0 <= th <= 1.0
-    assert onp.hermite_root(0.0, -1.0, -1.0, -1.0) == 0.0
-    assert onp.hermite_root(1.0, 0.0, -1.0, -1.0) == 1.0
+    for _ in range(300):    # a cubic is reproduced exactly by its Hermite form, and its root is found
+        c = [rng.uniform(0.1, 5), -rng.uniform(0.5, 15), rng.uniform(-1, 1), rng.uniform(-.3, .3)]
+        P_ = np.polynomial.Polynomial(c)
+        x0, x1 = P_(0.0), P_(1.0)
+        cc = onp.cubic_coeffs(x0, x1, P_.deriv()(0.0), P_.deriv()(1.0))
+        np.testing.assert_allclose(cc, c, atol=1e-12)
+        if x0 > 0 > x1:
+            th = onp.poly_root01(cc, x0, x1)
+            assert 0 <= th <= 1 and abs(P_(th)) < 1e-12
+    for _ in range(300):    # wild inputs: stays inside the bracket
+        x0, x1 = rng.uniform(0.01, 10), -rng.uniform(0.01, 10)
+        cc = onp.cubic_coeffs(x0, x1, rng.normal() * 10, rng.normal() * 10)
+        assert 0.0 <= onp.poly_root01(cc, x0, x1) <= 1.0
+    assert onp.poly_root01([0.0, -1.0, 0, 0], 0.0, -1.0) == 0.0
+    assert onp.poly_root01([1.0, -1.0, 0, 0], 1.0, 0.0) == 1.0
+
+
+def test_event_state_lands_on_the_ground(P, g4):
+    ev = np.nonzero(g4["status"] == 1)[0][:40]
+    for i in ev:
+        u = onp.denormalize_action(g4["action"][i])
+        y, st = onp.sim_step_fixed(g4["pre"][i], u, float(g4["m0"][i]), P.dt, "rk4")
+        assert st == 1 and abs(y[0]) < 1e-9      # the position correction removes the residual height
 
 
 def test_philox_known_answers():
