@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--variant", default="raw", choices=["raw", "wrapped"],
                     help="raw = Rocket6DOF.step (189 B); wrapped = fused make_env() stack (201 B)")
     ap.add_argument("--pool", type=int, default=8, help="number of pre-generated action buffers")
+    ap.add_argument("--burnin", type=int, default=300,
+                    help="untimed auto-reset steps run once after reset(), before warmup: all envs start in lockstep, "
+                         "so without it the timed region would sit on the first mass-termination wave instead of the "
+                         "steady mix of flight phases")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -122,6 +126,8 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = [(torch.rand((n, 3), generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(args.pool)]
     env.reset()
+    for k in range(args.burnin):
+        env.step_async(pool[k % args.pool])
 
     def barrier():
         if world > 1:
@@ -176,7 +182,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{n} envs/GPU x {world} GPU, {args.integrator} dt={dt} fp32, {args.variant} "
-                                   f"Rocket6DOF.step, random actions, auto-reset",
+                                   f"Rocket6DOF.step, random actions, auto-reset, {args.burnin} burn-in steps",
                        "envs_total": total, "integrator": args.integrator, "dt": dt, "variant": args.variant,
                        "bytes_per_env_step": bytes_per, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

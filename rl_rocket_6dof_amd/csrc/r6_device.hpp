@@ -216,6 +216,7 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
             rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, k);
 #pragma unroll
             for (int i = 0; i < kDyn; ++i) {
+                if (i == 10) continue;   // d(omega_x)/dt == 0 exactly (rhs13): omega_x stays y0[10]
                 y1[i] = fmaf(w, k[i], y1[i]);
                 yt[i] = fmaf(an, k[i], y0[i]);
             }
@@ -255,14 +256,19 @@ __device__ __forceinline__ float poly_root01(const float (&c)[N], float x0, floa
     return th;
 }
 
-// One env step of the simulator (sim:69-104) with fixed sub-steps.  Returns status (1 = ground).
+// One env step of the simulator (sim:69-104) with fixed sub-steps.
 //
 // Ground event (oracle_np.event_step_rk4): theta = root of the cubic Hermite interpolant of x over
-// the sub-step, then the SAME step map is applied again with the step shortened to theta*h -- a
-// second trip through one loop body, executed only by waves that hold a crossing lane, so the event
-// costs no registers and no second copy of the integrator.  A final Newton correction in time
-// (positions only) puts the state on x = 0.
-template <int INTEG>
+// the sub-step, then the SAME step map is applied again with the step shortened to theta*h, and a
+// final Newton correction in time (positions only) puts the state on x = 0.
+//
+// EVENTS = true : full semantics, returns status (1 = ground event handled).
+// EVENTS = false: hot-loop flavour -- the step map is applied once per sub-step; if a sub-step
+//                 crosses the ground the function stops and returns 1 WITHOUT producing the event
+//                 state (the caller re-runs that env through the EVENTS = true flavour in its dense
+//                 deferred pass).  This keeps the rare second trip through the integrator out of
+//                 the wave-divergent hot loop.
+template <int INTEG, bool EVENTS>
 __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J,
                                          float dt, int nsub) {
     const float h = dt / (float)nsub;
@@ -273,7 +279,7 @@ __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Co
         float y1[kDyn];
         float hs = h;
 #pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < (EVENTS ? 2 : 1); ++pass) {
             step_map<INTEG>(y, mass, c, J, hs, y1);
             if (pass == 1) {
                 if constexpr (INTEG == R6_RK4) {
@@ -288,6 +294,7 @@ __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Co
             }
             if (!crossing(y[0], y1[0])) break;
             status = 1;
+            if constexpr (!EVENTS) break;
             float th;
             if constexpr (INTEG == R6_RK4) {
                 const float d0 = h * y[3], d1 = h * y1[3];

@@ -98,9 +98,7 @@ __device__ __forceinline__ void reset_env_global(const R6Params& p, const R6Buff
     if (b.ep_return) b.ep_return[i] = 0.0f;
 }
 
-// Inputs of one 64-env tile, one lane = one env.  Loading is split from processing so that the tile
-// loop can issue the NEXT tile's loads before it computes the current one (software pipelining in
-// registers: every resident wave keeps ~4.6 KB of HBM reads in flight while its VALU work runs).
+// Inputs of one 64-env tile, one lane = one env.
 struct TileIn {
     float y[kDyn];
     float mass, m0, v0, a0, a1, a2, ep_ret;
@@ -191,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const R6Params p, const R6
         asm volatile("" :: "v"(c.tbx), "v"(c.tby), "v"(c.tbz), "v"(J.inv_jt), "v"(J.jdiff));
         y[3] += p.dt * c.mdot;
 #else
-        const int status = integrate<INTEG>(y, mass, c, J, p.dt, p.n_substeps);
+        const int status = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
 #endif
 
         // ---- termination (env:213, :591-593), reward (env:215, :228-229, :317-402),
@@ -296,31 +294,21 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const R6Params p, const R6
         wave_lds_sync();  // before the next tile overwrites the LDS tile
     };
 
-#ifdef R6_STAGGER   // experiment: de-phase the co-resident workgroups of a CU
-    {
-        const int cls = (blockIdx.x / 256) & 3;
-        for (int k = 0; k < cls; ++k) __builtin_amdgcn_s_sleep(R6_STAGGER);
-    }
-#endif
-    // Tile loop, software-pipelined: the loads of tile k+1 are issued before tile k is computed.
+    // Tile loop.  (Measured alternatives that did not pay at N = 2^20, where the loop is VALU-bound:
+    // register prefetch of the next tile -- +30 VGPRs, one wave per SIMD less, no gain; deferring
+    // ground-event envs to the dense pass -- its serial tail per workgroup costs more than the
+    // divergence it removes.)
     const int64_t n_full = n >> 6;  // tiles [0, n_full) are full; tile n_full (if any) is partial
-    TileIn nxt;
-    if (t_first < n_full)
-        load_tile<SHAPING, true>(b, has_ep, t_first * 64, lane, nxt);
-    else if (t_first < n_tiles)
-        load_tile<SHAPING, false>(b, has_ep, t_first * 64, lane, nxt);
 #pragma unroll 1
     for (int64_t t = t_first; t < n_tiles; t += nw) {
-        const TileIn cur = nxt;
-        const int64_t tn = t + nw;
-        if (tn < n_full)
-            load_tile<SHAPING, true>(b, has_ep, tn * 64, lane, nxt);
-        else if (tn < n_tiles)
-            load_tile<SHAPING, false>(b, has_ep, tn * 64, lane, nxt);
-        if (t < n_full)
+        TileIn cur;
+        if (t < n_full) {
+            load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
             process_tile(t * 64, cur, std::true_type{});
-        else
+        } else {
+            load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
             process_tile(t * 64, cur, std::false_type{});
+        }
     }
 
     // __syncthreads() drains every wave's outstanding stores (s_waitcnt vmcnt(0)) before the barrier,
@@ -386,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void sim_step_kernel(const R6Params p, floa
     float mass = state[13 * ld + i];
     const Control c = make_control_physical(u[3 * i + 0], u[3 * i + 1], u[3 * i + 2]);
     const Inertia J = make_inertia(epconst[i]);
-    const int st = integrate<INTEG>(y, mass, c, J, p.dt, p.n_substeps);
+    const int st = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
 #pragma unroll
     for (int j = 0; j < kDyn; ++j) state[j * ld + i] = y[j];
     state[13 * ld + i] = mass;

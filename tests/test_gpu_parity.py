@@ -154,8 +154,10 @@ def test_g5_reward_known_answers(torch_cuda, cfg, P):
 
 def test_g3_free_running_episodes(torch_cuda, cfg, P):
     """Whole reference episodes replayed open-loop in fp32 from the recorded x0 with the recorded
-    actions: the episode must end on the same step for the same reason; trajectory drift (fp32
-    accumulation vs the reference's float64) is reported and bounded at 1e-4 scaled."""
+    actions: the episode must end on the same step for the same reason.  Trajectory drift (fp32
+    accumulation over 100-250 steps vs the reference's float64 free run) is reported and bounded at
+    1e-4 of each component's range (the observation normaliser; for z, whose normaliser is the
+    degenerate 1 m, the +-180 m bound)."""
     torch = torch_cuda
     from rl_rocket_6dof_amd import BatchedRocket6DOF
 
@@ -166,18 +168,20 @@ def test_g3_free_running_episodes(torch_cuda, cfg, P):
     env.set_state(G["x0"].astype(np.float32))
     lens = np.array([(G["episode"] == e).sum() for e in eps])
     starts = np.array([np.nonzero(G["episode"] == e)[0][0] for e in eps])
+    scale = P.normalizer.copy()
+    scale[2] = 180.0
     worst = 0.0
     for k in range(lens.max()):
         act = np.zeros((n, 3), np.float32)
         alive = k < lens
         act[alive] = G["action"][starts[alive] + k]
         obs, rew, done, _ = env.step(torch.as_tensor(act, device=env.device))
-        obs, done = obs.cpu().numpy(), done.cpu().numpy()
+        st, done = env.get_state().cpu().numpy(), done.cpu().numpy()
         for e in np.nonzero(alive)[0]:
             i = starts[e] + k
             assert bool(done[e]) == bool(G["done"][i]), f"episode {e} step {k}: done {done[e]} vs {G['done'][i]}"
-            worst = max(worst, assert_close_scaled(obs[e], G["obs"][i], 1.0, 1e-4, f"episode {e} step {k} obs"))
-    print(f"[G3 free-running] {n} episodes, {int(lens.sum())} steps, worst scaled obs drift {worst:.2e}")
+            worst = max(worst, assert_close_scaled(st[e], G["post"][i], scale, 1e-4, f"episode {e} step {k} state"))
+    print(f"[G3 free-running] {n} episodes, {int(lens.sum())} steps, worst scaled state drift {worst:.2e}")
 
 
 @pytest.mark.parametrize("name,integ,h", [("euler_0.04", "euler", 0.04), ("euler_0.1", "euler", 0.1),
