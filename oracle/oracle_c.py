@@ -1,0 +1,168 @@
+"""ctypes wrapper of the oracle's C restatement (oracle/oracle_c.c -> oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this.  ``make -C oracle`` (or ``__graft_entry__.build()``) builds the library with gcc."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+
+from . import oracle_np as onp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "liboracle.so")
+NS = 14
+
+
+class OcParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double), ("integrator", C.c_int32), ("n_substeps", C.c_int32), ("shaping", C.c_int32),
+        ("auto_reset", C.c_int32), ("max_gimbal", C.c_double), ("max_thrust", C.c_double),
+        ("norm", C.c_double * NS), ("bound_lo", C.c_float * 3), ("bound_hi", C.c_float * 3), ("pad_", C.c_float * 2),
+        ("alfa", C.c_double), ("beta", C.c_double), ("eta", C.c_double), ("gamma", C.c_double), ("kappa", C.c_double),
+        ("w_r_f", C.c_double), ("w_v_f", C.c_double), ("max_r_f", C.c_double), ("max_v_f", C.c_double),
+        ("att_traj", C.c_double * 3), ("att_land", C.c_double * 3),
+        ("land_radius", C.c_double), ("land_vmax", C.c_double), ("omega_lim", C.c_double * 3), ("waypoint", C.c_double),
+        ("ic_lo", C.c_float * NS), ("ic_range", C.c_float * NS),
+        ("clip_reward", C.c_int32), ("max_episode_steps", C.c_int32), ("clip_lo", C.c_double), ("clip_hi", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load(build: bool = True):
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "oracle_c.c")):
+        if not build:
+            raise ImportError(f"{LIB} not built (run `make -C oracle`)")
+        subprocess.run(["make", "-s", "-C", HERE], check=True)
+    lib = C.CDLL(LIB)
+    lib.oc_params_size.restype = C.c_size_t
+    lib.oc_num_threads.restype = C.c_int
+    lib.oc_sim_step.restype = C.c_int
+    lib.oc_sim_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int]
+    lib.oc_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    lib.oc_reset_sample.argtypes = [C.POINTER(OcParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.oc_env_step.argtypes = [C.POINTER(OcParams)] + [C.c_void_p] * 11 + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]
+    assert lib.oc_params_size() == C.sizeof(OcParams), (lib.oc_params_size(), C.sizeof(OcParams))
+    _lib = lib
+    return lib
+
+
+def make_params(env_config: dict, integrator="rk4", n_substeps=1, dt=None, auto_reset=False, clip_reward=None,
+                max_episode_steps=0) -> OcParams:
+    P = onp.OracleParams.from_config(env_config)
+    p = OcParams()
+    p.dt = P.dt if dt is None else dt
+    p.integrator = 1 if integrator == "rk4" else 0
+    p.n_substeps = n_substeps
+    p.shaping = 0 if P.shaping == "acceleration" else 1
+    p.auto_reset = int(auto_reset)
+    p.max_gimbal, p.max_thrust = float(onp.MAX_GIMBAL), onp.MAX_THRUST
+    lo = (P.ic_mean - P.ic_range / np.float32(2)).astype(np.float32)
+    for j in range(NS):
+        p.norm[j] = P.normalizer[j]
+        p.ic_lo[j] = float(lo[j])
+        p.ic_range[j] = float(P.ic_range[j])
+    for j in range(3):
+        p.bound_lo[j], p.bound_hi[j] = float(P.bounds_low[j]), float(P.bounds_high[j])
+        p.att_traj[j], p.att_land[j] = P.attitude_traj_limit[j], P.landing_attitude_limit[j]
+        p.omega_lim[j] = P.omega_lim[j]
+    c = P.coeff
+    p.alfa, p.beta, p.eta, p.gamma, p.kappa = c["alfa"], c["beta"], c["eta"], c["gamma"], c["kappa"]
+    p.w_r_f, p.w_v_f, p.max_r_f, p.max_v_f = c["w_r_f"], c["w_v_f"], c["max_r_f"], c["max_v_f"]
+    p.land_radius, p.land_vmax, p.waypoint = P.target_r, P.maximum_v, P.waypoint
+    if clip_reward is not None:
+        p.clip_reward, p.clip_lo, p.clip_hi = 1, clip_reward[0], clip_reward[1]
+    p.max_episode_steps = max_episode_steps
+    return p
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchOracle:
+    """N envs stepped by the C restatement (float64 state, AoS)."""
+
+    def __init__(self, n, env_config, seed=42, env_offset=0, track=False, **kw):
+        self.lib = load()
+        self.p = make_params(env_config, **kw)
+        self.n, self.seed, self.env_offset = n, seed, env_offset
+        self.state = np.zeros((n, NS))
+        self.epconst = np.zeros((n, 2))
+        self.obs = np.zeros((n, NS), np.float32)
+        self.reward = np.zeros(n)
+        self.done = np.zeros(n, np.uint8)
+        self.flags = np.zeros(n, np.uint8)
+        self.terms = np.zeros((n, 7))
+        self.final_obs = np.zeros((n, NS), np.float32)
+        self.ep_step = np.zeros(n, np.uint32) if track else None
+        self.ep_return = np.zeros(n) if track else None
+        self.step_count = 0
+
+    def set_state(self, states, m0=None, v0=None):
+        self.state[:] = states
+        self.epconst[:, 0] = self.state[:, 13] if m0 is None else m0
+        self.epconst[:, 1] = np.linalg.norm(self.state[:, 3:6], axis=1) if v0 is None else v0
+
+    def reset(self, step_index):
+        ic = np.zeros(NS, np.float32)
+        for i in range(self.n):
+            self.lib.oc_reset_sample(C.byref(self.p), self.seed, self.env_offset + i, step_index, _vp(ic))
+            self.state[i] = ic
+        self.set_state(self.state)
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.float32)
+        self.step_count += 1
+        self.lib.oc_env_step(C.byref(self.p), _vp(self.state), _vp(self.epconst), _vp(a), _vp(self.obs), _vp(self.reward),
+                             _vp(self.done), _vp(self.flags), _vp(self.terms), _vp(self.ep_step), _vp(self.ep_return),
+                             _vp(self.final_obs), self.seed, self.step_count, self.env_offset, self.n)
+        return self.obs, self.reward, self.done
+
+
+def sim_step(y, u, m0, dt, integrator="rk4", n_substeps=1):
+    lib = load()
+    y = np.array(y, dtype=np.float64)
+    u = np.ascontiguousarray(u, np.float32)
+    st = lib.oc_sim_step(_vp(y), _vp(u), float(m0), float(dt), 1 if integrator == "rk4" else 0, n_substeps)
+    return y, st
+
+
+def rhs(y, u, m0):
+    lib = load()
+    y = np.ascontiguousarray(y, np.float64)
+    u = np.ascontiguousarray(u, np.float32)
+    dy = np.zeros(NS)
+    lib.oc_rhs(_vp(y), _vp(u), float(m0), _vp(dy))
+    return dy
+
+
+def benchmark(seconds: float, n: int = 1 << 16):
+    """'Best CPU' line: fixed-step RK4 C restatement, OpenMP over envs, all host cores."""
+    from rl_rocket_6dof_amd import default_env_config
+
+    env = BatchOracle(n, default_env_config(), auto_reset=True)
+    env.reset(0)
+    rng = np.random.RandomState(0)
+    acts = [rng.uniform(-1, 1, (n, 3)).astype(np.float32) for _ in range(4)]
+    for k in range(3):
+        env.step(acts[k % 4])
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        env.step(acts[steps % 4])
+        steps += 1
+    el = time.perf_counter() - t0
+    th = env.lib.oc_num_threads()
+    return {"value": steps * n / el, "unit": "env-steps/s", "cores": th, "kind": "port",
+            "sample": f"{steps} steps of {n} envs, fixed-step RK4 dt 0.1 (the HIP kernel's algorithm in C/float64, "
+                      f"OpenMP, auto-reset) in {el:.1f} s on {th} threads"}

@@ -52,9 +52,9 @@ def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if dist.get_backend() == "nccl":
             vec = vec.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        table = torch.empty((dist.get_world_size(), NUM_STATS), dtype=torch.float64, device=vec.device)
-        dist.all_gather_into_tensor(table, vec)
-        table = table.cpu()
+        rows = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, vec)          # RCCL all-gather on GPU ranks, gloo on CPU ranks
+        table = torch.stack(rows).cpu()
     else:
         table = vec.reshape(1, NUM_STATS)
     tot = table.sum(0)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# GPU box: rocprofv3 kernel-trace/stats of the default bench command + PMC traffic passes -> gpurun_out/profile_<tag>/
+set -e
+TAG=${1:-r1}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+done
+python3 - <<PY
+import csv, glob, json
+out = {}
+f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+out["kernel_stats_top"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows[:6]]
+tr = glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True)[0]
+st = [r for r in csv.DictReader(open(tr)) if "step_kernel" in r["Kernel_Name"]]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in st][-200:]
+out["step_kernel_timed_region"] = {"launches": len(d), "avg_us": sum(d) / len(d), "min_us": min(d), "max_us": max(d),
+                                   "vgpr": st[-1]["VGPR_Count"], "sgpr": st[-1]["SGPR_Count"], "lds": st[-1]["LDS_Block_Size"],
+                                   "grid": st[-1]["Grid_Size_X"], "workgroup": st[-1]["Workgroup_Size_X"]}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c][-50:]
+    out[c + "_KB_per_launch_raw"] = sum(v) / len(v)
+# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 128-B read requests at 64 B -> double it; WRITE_SIZE exact
+fetch = out["FETCH_SIZE_KB_per_launch_raw"] * 1024 * 2
+write = out["WRITE_SIZE_KB_per_launch_raw"] * 1024
+out["hbm_bytes_per_launch"] = fetch + write
+out["hbm_read_bytes_per_launch_corrected"] = fetch
+out["hbm_write_bytes_per_launch"] = write
+out["algorithmic_bytes_per_launch"] = 189 * (1 << 20)
+json.dump(out, open("$OUT/summary.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+tail -1 $OUT/bench_under_trace.log

@@ -1,0 +1,101 @@
+"""Pins the oracle's C restatement (oracle/oracle_c.c) against the golden vectors and against the
+numpy oracle.  CPU-only."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import assert_close_scaled, load_golden
+from oracle import oracle_c as oc
+from oracle import oracle_np as onp
+
+
+# natural magnitude of the 7 reward terms (see tests/test_gpu_parity.py): the O(1..40) terms are float32
+# quantities in the reference itself (float32 norms), so they cannot agree below ~1e-6 absolute
+TERM_SCALE = np.array([1e-2, 1e-2, 1e-2, 1.0, 1.0, 1.0, 1.0])
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return json.loads(str(load_golden("g3_env_rollouts.npz")["config"]))
+
+
+@pytest.fixture(scope="module")
+def P(cfg):
+    return onp.OracleParams.from_config(cfg)
+
+
+def test_g2_rhs(g2):
+    scale = np.array([1, 1, 1, 1, 1, 1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 1.0])
+    for i in range(0, len(g2["y"]), 3):
+        got = oc.rhs(g2["y"][i], g2["u"][i], float(g2["m0"][i]))
+        # glibc cosf/sinf vs numpy's float32 trig may differ by 1 ulp -> 1e-7 on the thrust direction
+        assert_close_scaled(got, g2["dy"][i], scale, 3e-7, f"C rhs {i}")
+
+
+@pytest.mark.parametrize("fixture", ["g3_env_rollouts.npz", "g4_ground_events.npz"])
+def test_env_step_vs_reference(cfg, P, fixture):
+    G = load_golden(fixture)
+    n = len(G["reward"])
+    env = oc.BatchOracle(n, cfg)
+    env.set_state(G["pre"], m0=G["m0"])
+    obs, rew, done = env.step(G["action"])
+    np.testing.assert_array_equal(done, G["done"])
+    np.testing.assert_array_equal((env.flags & 2) >> 1, G["bounds"])
+    np.testing.assert_array_equal(env.flags & 1, (G["status"] == 1).astype(np.uint8))
+    assert_close_scaled(env.state, G["post"], P.normalizer[None, :], 2e-6, "C post-state vs reference")
+    assert_close_scaled(obs, G["obs"], 1.0, 2e-6, "C obs vs reference")
+    assert_close_scaled(env.terms, G["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference")
+    assert_close_scaled(rew, G["reward"], 1e-1, 2e-5, "C reward vs reference")
+
+
+def test_g5_reward(cfg, P, g5):
+    n = len(g5["state"])
+    env = oc.BatchOracle(n, cfg, dt=1e-9)
+    env.set_state(g5["state"].astype(np.float32).astype(np.float64))
+    env.step(g5["action"])
+    np.testing.assert_array_equal((env.flags & 2) >> 1, g5["bounds"])
+    assert_close_scaled(env.terms, g5["terms"], TERM_SCALE, 5e-6, "C G5 reward terms")
+
+
+def test_matches_numpy_oracle_incl_euler_and_velocity(cfg):
+    G = load_golden("g4_ground_events.npz")
+    idx = np.arange(0, len(G["reward"]), 11)
+    for integ, shaping in (("euler", "acceleration"), ("rk4", "velocity")):
+        c2 = json.loads(json.dumps(cfg))
+        c2["reward_shaping_type"] = shaping
+        c2["landing_params"]["waypoint"] = 40
+        Pn = onp.OracleParams.from_config(c2)
+        env = oc.BatchOracle(len(idx), c2, integrator=integ)
+        v0 = np.linalg.norm(G["pre"][idx][:, 3:6], axis=1) + 5
+        env.set_state(G["pre"][idx], m0=G["m0"][idx], v0=v0)
+        env.step(G["action"][idx])
+        for k, i in enumerate(idx):
+            o = onp.env_step(G["pre"][i], float(G["m0"][i]), G["action"][i], Pn, integ, v0=float(v0[k]))
+            assert bool(env.done[k]) == o["done"]
+            assert_close_scaled(env.state[k], o["post"], Pn.normalizer, 2e-8, f"{integ} post {i}")   # glibc vs numpy float32 trig: 1 ulp
+            assert_close_scaled(env.terms[k], o["terms"], TERM_SCALE, 5e-6, f"{integ}/{shaping} terms {i}")
+
+
+def test_reset_stream_bit_exact_with_numpy_oracle(cfg, P):
+    env = oc.BatchOracle(64, cfg, seed=99, env_offset=5_000_000_000)
+    env.reset(step_index=(1 << 60) + 3)
+    for i in range(0, 64, 7):
+        want = onp.reset_sample(99, 5_000_000_000 + i, (1 << 60) + 3, P)
+        plain = [0, 1, 2, 3, 4, 5, 10, 11, 12, 13]
+        np.testing.assert_array_equal(env.state[i, plain].astype(np.float32), want[plain])
+        np.testing.assert_allclose(env.state[i, 6:10], want[6:10], atol=1.2e-7)
+
+
+def test_auto_reset_and_counters(cfg):
+    n = 256
+    env = oc.BatchOracle(n, cfg, auto_reset=True, track=True, clip_reward=(-1, 100), max_episode_steps=30)
+    env.reset(0)
+    rng = np.random.RandomState(0)
+    total_done = 0
+    for k in range(30):
+        env.step(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
+        total_done += int(env.done.sum())
+        assert np.all(env.reward <= 100) and np.all(env.reward >= -1)
+    assert env.done.all() and ((env.flags & 4) != 0).sum() > n // 2     # TimeLimit at step 30
+    assert np.all(env.ep_step == 0) and np.all(env.ep_return == 0)      # everything was just reset
