@@ -105,13 +105,17 @@ def main():
     from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
     from rl_rocket_6dof_amd import dist as r6dist
 
-    rank, world, local = r6dist.init_from_env()
+    # R6_DIST_BACKEND=gloo + R6_FORCE_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); the driver's real runs use the defaults (nccl, LOCAL_RANK).
+    rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product has no CPU path)")
+    local = int(os.environ.get("R6_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    on_gpu_pg = world > 1 and dist.get_backend() == "nccl"
 
     n = args.envs_per_gpu
     total = n * world
@@ -150,7 +154,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps      # mean launch-to-launch duration on the stream
 
     if world > 1:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev if on_gpu_pg else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(t[0]), float(t[1])
         # the one collective of the design (episode summaries), exercised outside the timed region

@@ -56,7 +56,7 @@ enum {
     R6_STAT_LANDED = 7    /* episodes whose last step met all landing conditions (goal term) */
 };
 #define R6_BLOCK 256      /* threads per workgroup (4 wave64) */
-#define R6_MAX_BLOCKS 2048 /* upper bound of the persistent step grid = rows of `stats` */
+#define R6_MAX_BLOCKS 16384 /* upper bound of the step grid = rows of `stats` */
 
 /* Kernel constants: everything config.yaml's env_config can change (rocket_env.py:22-178),
  * pre-digested on the host.  All members are 4 bytes wide (no padding anywhere). */

@@ -40,7 +40,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("R6_FORCE_DEVICE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -21,7 +21,7 @@ ACTION_DIM = 3
 NUM_TERMS = 7
 NUM_STATS = 8
 BLOCK = 256
-MAX_BLOCKS = 2048
+MAX_BLOCKS = 16384
 
 EULER, RK4 = 0, 1
 SHAPING_ACCELERATION, SHAPING_VELOCITY = 0, 1
