@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's main_6DOF.py:start_training (without wandb / xvfb): PPO on the fused
+make_env() stack (RemoveMassFromObs + ClipReward(-1,100) + TimeLimit(max_time/timestep) + Monitor), every
+environment on the GPU.
+
+    python examples/train_ppo.py --envs 65536 --timesteps 2e8
+    torchrun --nproc-per-node 8 examples/train_ppo.py --envs 8388608      # env-sharded, RCCL grad all-reduce
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rl_rocket_6dof_amd import dist as r6dist
+from rl_rocket_6dof_amd import load_config
+from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=1 << 16, help="total environments (sharded over the ranks)")
+    ap.add_argument("--timesteps", type=float, default=5e7)
+    ap.add_argument("--n-steps", type=int, default=64)
+    ap.add_argument("--batch-size", type=int, default=1 << 16)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--net-arch", default="128,64", help="main_6DOF.py:113 uses [128, 64]; SB3 default is 64,64")
+    ap.add_argument("--config", default=None)
+    args = ap.parse_args()
+
+    rank, world, local = r6dist.init_from_env()
+    torch.cuda.set_device(local)
+    sb3_config, env_config = load_config(args.config)
+    max_steps = int(sb3_config["max_time"] / env_config["timestep"])          # main_6DOF.py:31
+    env = r6dist.make_sharded_env(args.envs, env_config, device=f"cuda:{local}", remove_mass=True,
+                                  clip_reward=(-1, 100), max_episode_steps=max_steps, seed=env_config["seed"])
+    cfg = PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, n_epochs=args.epochs, learning_rate=args.lr,
+                    net_arch=tuple(int(x) for x in args.net_arch.split(",")), seed=env_config["seed"])
+    algo = PPO(env, cfg)
+    t0 = time.time()
+
+    def log(info):
+        if rank == 0:
+            info = dict(info, wall_s=round(time.time() - t0, 1), sps=round(info["timesteps"] / (time.time() - t0)))
+            print(json.dumps({k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()}), flush=True)
+
+    algo.learn(int(args.timesteps), log=log)
+
+
+if __name__ == "__main__":
+    main()

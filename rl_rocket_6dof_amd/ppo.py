@@ -1,0 +1,232 @@
+"""On-device PPO for ``BatchedRocket6DOF`` (BASELINE config 5).
+
+The reference trains with stable-baselines3 1.6.0 ``PPO("MlpPolicy", env, policy_kwargs={'net_arch':
+[128, 64]})`` on ONE env (reference main_6DOF.py:107-139; defaults recorded in its checkpoints:
+n_steps 2048, batch 64, epochs 10, lr 3e-4, gamma 0.99, lambda 0.95, clip 0.2, ent 0, vf 0.5,
+max-grad-norm 0.5).  SB3 is not a dependency here and its Python loop over a list of N info dicts cannot
+serve N = 2^20 environments, so this is an own implementation of the same algorithm and defaults whose
+rollout buffer, advantage computation and minibatching stay in HBM next to the environment state:
+
+  * policy = SB3 ``MlpPolicy``: separate tanh MLPs for actor and critic, orthogonal init (gains sqrt 2,
+    0.01 for the action head, 1 for the value head), state-independent ``log_std`` initialised to 0;
+  * actions are clipped to the Box before ``env.step`` (SB3 ``OnPolicyAlgorithm.collect_rollouts``),
+    the un-clipped sample is what the log-probability is taken of;
+  * time-limit truncations bootstrap with gamma * V(terminal_observation) (SB3 >= 1.5);
+  * GAE(lambda), advantage normalisation per minibatch, clipped surrogate, MSE value loss, global
+    gradient-norm clipping -- as in SB3's ``PPO.train``.
+
+Multi-GPU: envs are sharded per rank (``dist.make_sharded_env``); gradients are averaged with one
+bucketed all-reduce per optimiser step (RCCL), episode summaries are all-gathered once per rollout.
+PPO learning curves cannot be compared with the reference bit for bit ("parity unpinned" -- different
+sampling, one env vs millions); the tests check the algebra (GAE, losses) against closed forms and that
+the return improves.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .params import FLAG_TRUNCATED
+
+
+@dataclass
+class PPOConfig:
+    n_steps: int = 32                # rollout length per env (SB3 default 2048 for ONE env)
+    batch_size: int = 1 << 16        # minibatch size (SB3 default 64)
+    n_epochs: int = 10
+    learning_rate: float = 3e-4
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_range: float = 0.2
+    ent_coef: float = 0.0
+    vf_coef: float = 0.5
+    max_grad_norm: float = 0.5
+    normalize_advantage: bool = True
+    net_arch: Sequence[int] = (64, 64)   # SB3 MlpPolicy default; the reference's training run used [128, 64]
+    log_std_init: float = 0.0
+    seed: int = 42
+
+
+def _mlp(sizes, out_dim, out_gain):
+    layers, last = [], sizes[0]
+    for h in sizes[1:]:
+        lin = nn.Linear(last, h)
+        nn.init.orthogonal_(lin.weight, gain=math.sqrt(2))
+        nn.init.zeros_(lin.bias)
+        layers += [lin, nn.Tanh()]
+        last = h
+    head = nn.Linear(last, out_dim)
+    nn.init.orthogonal_(head.weight, gain=out_gain)
+    nn.init.zeros_(head.bias)
+    return nn.Sequential(*layers, head)
+
+
+class ActorCritic(nn.Module):
+    """SB3 ``ActorCriticPolicy`` with a diagonal Gaussian action distribution."""
+
+    def __init__(self, obs_dim: int, act_dim: int, net_arch=(64, 64), log_std_init: float = 0.0):
+        super().__init__()
+        self.pi = _mlp([obs_dim, *net_arch], act_dim, 0.01)
+        self.vf = _mlp([obs_dim, *net_arch], 1, 1.0)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+
+    def value(self, obs):
+        return self.vf(obs).squeeze(-1)
+
+    def _logp(self, mean, actions):
+        var = torch.exp(2 * self.log_std)
+        return (-0.5 * ((actions - mean) ** 2 / var + 2 * self.log_std + math.log(2 * math.pi))).sum(-1)
+
+    @torch.no_grad()
+    def act(self, obs, generator=None, deterministic=False):
+        mean = self.pi(obs)
+        if deterministic:
+            actions = mean
+        else:
+            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            actions = mean + noise * torch.exp(self.log_std)
+        return actions, self.value(obs), self._logp(mean, actions)
+
+    def evaluate(self, obs, actions):
+        mean = self.pi(obs)
+        entropy = (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std).sum().expand(obs.shape[0])
+        return self.value(obs), self._logp(mean, actions), entropy
+
+
+def compute_gae(rewards, values, dones, last_values, gamma: float, lam: float):
+    """SB3 ``RolloutBuffer.compute_returns_and_advantage``.  rewards/values/dones: (T, N) with
+    dones[t] = episode ended AT step t (so the value after it is not bootstrapped); last_values: (N,)."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_values)
+    for t in reversed(range(T)):
+        next_v = last_values if t == T - 1 else values[t + 1]
+        nonterm = 1.0 - dones[t]
+        delta = rewards[t] + gamma * next_v * nonterm - values[t]
+        last = delta + gamma * lam * nonterm * last
+        adv[t] = last
+    return adv, adv + values
+
+
+class PPO:
+    def __init__(self, env, config: Optional[PPOConfig] = None, policy: Optional[ActorCritic] = None):
+        self.env = env
+        self.cfg = cfg = config or PPOConfig()
+        self.device = env.device
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        torch.manual_seed(cfg.seed)          # identical initial weights on every rank
+        self.policy = (policy or ActorCritic(env.obs_dim, 3, cfg.net_arch, cfg.log_std_init)).to(self.device)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5)
+        rank = dist.get_rank() if self.world > 1 else 0
+        self.gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1000003 * rank)
+        n, T = env.num_envs, cfg.n_steps
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.buf_obs = torch.zeros((T, n, env.obs_dim), **f32)
+        self.buf_act = torch.zeros((T, n, 3), **f32)
+        self.buf_logp = torch.zeros((T, n), **f32)
+        self.buf_val = torch.zeros((T, n), **f32)
+        self.buf_rew = torch.zeros((T, n), **f32)
+        self.buf_done = torch.zeros((T, n), **f32)
+        self._obs = None
+        self.num_timesteps = 0
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def collect_rollouts(self):
+        env, cfg = self.env, self.cfg
+        if self._obs is None:
+            self._obs = env.reset().clone()
+        for t in range(cfg.n_steps):
+            actions, values, logp = self.policy.act(self._obs, generator=self.gen)
+            self.buf_obs[t].copy_(self._obs)
+            self.buf_act[t].copy_(actions)
+            self.buf_val[t].copy_(values)
+            self.buf_logp[t].copy_(logp)
+            obs, rew, done, _ = env.step(actions.clamp(-1.0, 1.0).contiguous())   # SB3 clips to the Box
+            rew = rew.clone()
+            if env.max_episode_steps and env.flags is not None and env.final_obs is not None:
+                trunc = (env.flags & FLAG_TRUNCATED) != 0          # TimeLimit.truncated -> bootstrap
+                if bool(trunc.any()):
+                    idx = trunc.nonzero(as_tuple=True)[0]
+                    rew[idx] += cfg.gamma * self.policy.value(env.final_obs[idx])
+            self.buf_rew[t].copy_(rew)
+            self.buf_done[t].copy_(done.to(torch.float32))
+            self._obs = obs.clone()           # env.obs is overwritten by the next step
+        self.num_timesteps += cfg.n_steps * env.num_envs * self.world
+        last_values = self.policy.value(self._obs)
+        self.adv, self.ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done, last_values, cfg.gamma, cfg.gae_lambda)
+
+    def _sync_grads(self):
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.policy.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])          # one bucket: ~10^4 parameters
+        if dist.get_backend() != "nccl":
+            flat = flat.cpu()
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat = flat.to(grads[0].device) / self.world
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def train(self) -> Dict[str, float]:
+        cfg = self.cfg
+        T, n = self.buf_rew.shape
+        total = T * n
+        obs = self.buf_obs.reshape(total, -1)
+        act = self.buf_act.reshape(total, 3)
+        old_logp, old_val = self.buf_logp.reshape(total), self.buf_val.reshape(total)
+        adv, ret = self.adv.reshape(total), self.ret.reshape(total)
+        bs = min(cfg.batch_size, total)
+        stats = dict(pg_loss=0.0, v_loss=0.0, entropy=0.0, clip_frac=0.0, approx_kl=0.0, n=0)
+        for _ in range(cfg.n_epochs):
+            perm = torch.randperm(total, device=self.device, generator=self.gen)
+            for s in range(0, total - bs + 1, bs):
+                mb = perm[s:s + bs]
+                a = adv[mb]
+                if cfg.normalize_advantage and bs > 1:
+                    a = (a - a.mean()) / (a.std() + 1e-8)
+                values, logp, entropy = self.policy.evaluate(obs[mb], act[mb])
+                ratio = torch.exp(logp - old_logp[mb])
+                pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+                v_loss = torch.nn.functional.mse_loss(ret[mb], values)
+                ent = -entropy.mean()
+                loss = pg + cfg.ent_coef * ent + cfg.vf_coef * v_loss
+                self.opt.zero_grad(set_to_none=False)
+                loss.backward()
+                self._sync_grads()
+                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
+                self.opt.step()
+                with torch.no_grad():
+                    stats["pg_loss"] += float(pg)
+                    stats["v_loss"] += float(v_loss)
+                    stats["entropy"] += float(-ent)
+                    stats["clip_frac"] += float(((ratio - 1).abs() > cfg.clip_range).float().mean())
+                    stats["approx_kl"] += float(((ratio - 1) - (logp - old_logp[mb])).mean())
+                    stats["n"] += 1
+        k = max(stats.pop("n"), 1)
+        return {key: v / k for key, v in stats.items()}
+
+    def learn(self, total_timesteps: int, log=None):
+        """Alternates rollouts and updates until ``total_timesteps`` env steps (whole job) are done.
+        Returns the per-iteration log (episode summaries are all-gathered across ranks)."""
+        from .dist import gather_episode_stats, summarize
+
+        history = []
+        while self.num_timesteps < total_timesteps:
+            self.collect_rollouts()
+            info = self.train()
+            if self.env.stats is not None:
+                tot, _ = gather_episode_stats(self.env.episode_stats(), device=self.device)
+                info.update(summarize(tot))
+            info["timesteps"] = self.num_timesteps
+            history.append(info)
+            if log is not None:
+                log(info)
+        return history

@@ -1,0 +1,160 @@
+"""CPU-only tests of the on-device PPO plumbing (rl_rocket_6dof_amd/ppo.py) on a tiny torch stand-in
+environment: GAE against a naive reference, the Gaussian policy against torch.distributions, the
+time-limit bootstrap, learning progress, and gradient averaging across 2 gloo ranks."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from rl_rocket_6dof_amd.params import FLAG_TRUNCATED
+from rl_rocket_6dof_amd.ppo import PPO, ActorCritic, PPOConfig, compute_gae
+
+
+class ToyEnv:
+    """N points on a line: obs = (x, 0...), action[0] = velocity command; reward = -|x|; episodes end by the
+    time limit only (so the truncation bootstrap is exercised)."""
+
+    def __init__(self, n, obs_dim=13, T=20, seed=0):
+        self.num_envs, self.obs_dim, self.device = n, obs_dim, torch.device("cpu")
+        self.max_episode_steps = T
+        self.g = torch.Generator().manual_seed(seed)
+        self.flags = torch.zeros(n, dtype=torch.uint8)
+        self.final_obs = torch.zeros((n, obs_dim))
+        self.stats = None
+        self.x = self.v = self.t = None
+
+    def _obs(self):
+        o = torch.zeros((self.num_envs, self.obs_dim))
+        o[:, 0], o[:, 1] = self.x, self.v
+        return o
+
+    def reset(self):
+        self.x = torch.rand(self.num_envs, generator=self.g) * 2 - 1
+        self.v = torch.zeros(self.num_envs)
+        self.t = torch.zeros(self.num_envs, dtype=torch.int64)
+        return self._obs()
+
+    def step(self, a):
+        self.x = self.x + 0.2 * a[:, 0].clamp(-1, 1)
+        self.t += 1
+        rew = -self.x.abs()
+        self.raw_reward_mean = float(rew.mean())
+        done = self.t >= self.max_episode_steps
+        self.flags = torch.where(done, torch.tensor(FLAG_TRUNCATED, dtype=torch.uint8), torch.tensor(0, dtype=torch.uint8))
+        self.final_obs = self._obs()
+        if done.any():
+            idx = done.nonzero(as_tuple=True)[0]
+            self.x[idx] = torch.rand(len(idx), generator=self.g) * 2 - 1
+            self.v[idx] = 0
+            self.t[idx] = 0
+        return self._obs(), rew, done, None
+
+
+def test_gae_matches_naive_reference():
+    torch.manual_seed(0)
+    T, n, gamma, lam = 7, 5, 0.99, 0.95
+    r, v = torch.randn(T, n), torch.randn(T, n)
+    d = (torch.rand(T, n) < 0.2).float()
+    last = torch.randn(n)
+    adv, ret = compute_gae(r, v, d, last, gamma, lam)
+    want = np.zeros((T, n))
+    for e in range(n):
+        for t in range(T):
+            a, coef = 0.0, 1.0
+            for k in range(t, T):
+                nv = last[e].item() if k == T - 1 else v[k + 1, e].item()
+                nt = 1.0 - d[k, e].item()
+                a += coef * (r[k, e].item() + gamma * nv * nt - v[k, e].item())
+                coef *= gamma * lam * nt
+                if nt == 0.0:
+                    break
+            want[t, e] = a
+    np.testing.assert_allclose(adv.numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ret.numpy(), want + v.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_policy_matches_torch_distributions_and_sb3_init():
+    torch.manual_seed(1)
+    pol = ActorCritic(13, 3, (64, 64))
+    assert [m.out_features for m in pol.pi if isinstance(m, torch.nn.Linear)] == [64, 64, 3]
+    assert float(pol.log_std.abs().max()) == 0.0                       # SB3 log_std_init = 0
+    w = pol.pi[-1].weight
+    assert abs(float((w @ w.T)[0, 0]) - 0.01 ** 2) < 1e-6              # orthogonal, gain 0.01
+    with torch.no_grad():
+        pol.log_std.copy_(torch.tensor([0.1, -0.3, 0.2]))
+    obs = torch.randn(32, 13)
+    a, v, logp = pol.act(obs)
+    dist_ = torch.distributions.Normal(pol.pi(obs), pol.log_std.exp())
+    np.testing.assert_allclose(logp.numpy(), dist_.log_prob(a).sum(-1).detach().numpy(), rtol=1e-5, atol=1e-5)
+    v2, logp2, ent = pol.evaluate(obs, a)
+    np.testing.assert_allclose(ent.detach().numpy(), dist_.entropy().sum(-1).detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(v2.detach().numpy(), v.numpy(), rtol=1e-6)
+
+
+def test_truncation_bootstrap_and_learning_progress():
+    env = ToyEnv(256, T=20)
+    cfg = PPOConfig(n_steps=40, batch_size=2048, n_epochs=6, learning_rate=3e-3, seed=3)
+    algo = PPO(env, cfg)
+    algo.collect_rollouts()
+    # every env is truncated at t = 20 and t = 40; the stored reward there is r + gamma * V(terminal obs)
+    assert algo.buf_done[19].all() and algo.buf_done[39].all() and algo.buf_done[:19].sum() == 0
+    x_after = algo.buf_obs[19, :, 0] + 0.2 * algo.buf_act[19, :, 0].clamp(-1, 1)
+    term_obs = torch.zeros((env.num_envs, env.obs_dim))
+    term_obs[:, 0] = x_after
+    with torch.no_grad():
+        want = -x_after.abs() + cfg.gamma * algo.policy.value(term_obs)
+    np.testing.assert_allclose(algo.buf_rew[19].numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    first = env.raw_reward_mean
+    for _ in range(20):
+        algo.collect_rollouts()
+        info = algo.train()
+        assert all(math.isfinite(v) for v in info.values())
+    assert env.raw_reward_mean > 0.25 * first, (first, env.raw_reward_mean)   # |x| shrinks >4x as the policy learns
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_ppo_host import ToyEnv
+
+    env = ToyEnv(64, T=10, seed=100 + rank)          # different data per rank
+    algo = PPO(env, PPOConfig(n_steps=20, batch_size=256, n_epochs=2, seed=5))
+    for _ in range(3):
+        algo.collect_rollouts()
+        algo.train()
+    flat = torch.cat([p.detach().reshape(-1) for p in algo.policy.parameters()])
+    q.put((rank, flat.numpy(), algo.num_timesteps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_averaging_keeps_replicas_identical():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])     # same init + averaged grads => same weights
+    assert res[0][2] == 3 * 20 * 64 * 2                     # timesteps count the whole job
