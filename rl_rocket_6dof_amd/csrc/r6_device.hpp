@@ -104,7 +104,7 @@ __device__ __forceinline__ Control make_control_physical(float dy, float dz, flo
 __device__ __forceinline__ Inertia make_inertia(float m0) {
     Inertia j;
     const float jt = m0 * kJtPerM;
-    j.inv_jt = 1.0f / jt;
+    j.inv_jt = frcp(jt);
     j.jdiff = m0 * kJxPerM - jt;
     return j;
 }
@@ -346,7 +346,9 @@ struct Quartic {
     float b2, b1, b0, ti;
 };
 
-__device__ __forceinline__ void quartic_newton(const Quartic& q, float& t, bool& left, bool& conv, bool allow_restart) {
+// General Newton step with the safeguards (monotone clamp, branch switch, restart): used by the rare
+// wave-uniform tail loop only.
+__device__ __forceinline__ void quartic_newton_safe(const Quartic& q, float& t, bool& left, bool& conv, bool allow_restart) {
     const float t2 = t * t;
     const float p = fmaf(fmaf(t2 + q.b2, t, q.b1), t, q.b0);
     const float dp = fmaf(fmaf(4.0f, t2, 2.0f * q.b2), t, q.b1);
@@ -384,14 +386,30 @@ __device__ __forceinline__ float t_go_quartic(float c2, float c1, float c0) {
         const float fuji = 2.002f * fmaxf(fsqrt(fabsf(q.b2)), fmaxf(m1, fsqrt(fsqrt(0.5f * fabsf(q.b0))))) + 1e-6f;
         t = left ? 0.0f : ((q.b1 >= 0.0f) ? tq : fuji);
     }
-    bool conv = false;
+    // Fast path: 8 bare Newton steps.  On the branch chosen above p' > 0 between the start and the root
+    // (convex branch right of the largest root / concave branch left of its only root), so no clamp
+    // is needed: an overshoot by round-off lands next to the root, where Newton simply steps back.
+    const float b2x2 = 2.0f * q.b2;
+    float step = 0.0f;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) quartic_newton(q, t, left, conv, false);
+    for (int it = 0; it < 8; ++it) {
+        const float t2 = t * t;
+        const float p = fmaf(fmaf(t2 + q.b2, t, q.b1), t, q.b0);
+        const float dp = fmaf(fmaf(4.0f, t2, b2x2), t, q.b1);
+        step = p * frcp(dp);
+        t -= step;
+    }
+    bool conv = fabsf(step) <= 4e-7f * t;   // also false for NaN / a fall off the branch (dp <= 0 => huge or negative step)
     if (__builtin_expect(__any(!conv || may_restart), 0)) {
         // tail: slow lanes, and the rare lanes that may have to restart on the concave branch
+        left = (p_i > 0.0f) && (dp_i >= 0.0f);
+        if (!(t > 0.0f) || !(t < 3.0e38f)) {   // re-seed a lane whose bare iteration went astray (NaN, <= 0, inf)
+            const float tq = fsqrt(0.5f * (fsqrt(fmaf(q.b2, q.b2, -4.0f * q.b0)) - q.b2));
+            t = left ? 0.0f : 2.002f * fmaxf(tq, fexp2(flog2(fmaxf(fabsf(q.b1), 1e-30f)) * (1.0f / 3.0f))) + 1e-6f;
+        }                                      // slow-but-healthy lanes simply continue from where they are
 #pragma unroll 1
-        for (int it = 0; it < 24; ++it) {
-            quartic_newton(q, t, left, conv, may_restart);
+        for (int it = 0; it < 40; ++it) {
+            quartic_newton_safe(q, t, left, conv, may_restart);
             if (__all(conv)) break;
         }
     }
