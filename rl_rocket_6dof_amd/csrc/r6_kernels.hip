@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
     const int64_t nw = (int64_t)gridDim.x * kWaves;
     const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
+    const bool opt_flags_terms = b.flags != nullptr || b.terms != nullptr;
 
     if (tid == 0) rq_count = 0;
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
@@ -195,34 +196,45 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
 #endif
 
         // ---- termination (env:213, :591-593), reward (env:215, :228-229, :317-402),
-        //      fused ClipReward / TimeLimit / Monitor (main_6DOF.py:33-51) ----------------------------
-        const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
-        bool done = (status != 0) || bnd;
+        //      fused ClipReward / TimeLimit / Monitor (main_6DOF.py:33-51).  In the RK4 instances the
+        //      ~40 parameters of this phase are re-read from the kernarg segment here (scalar loads, cache
+        //      hits) instead of living in SGPRs across the whole loop, where they spill (A/B: 43.8 -> 42.3
+        //      us); the short Euler loop has too little work to hide that latency and keeps them resident. --
+        bool bnd, done, truncated = false, landed;
+        float rew;
+        float terms7[R6_NUM_TERMS];
+        {
+            const R6Params pr = [&]() __attribute__((always_inline)) {
+                if constexpr (INTEG == R6_RK4) return load_params();
+                else return p;
+            }();
+            bnd = bounds_violation(pr, y[0], y[1], y[2]);
+            done = (status != 0) || bnd;
 #ifdef R6_ABLATE_REWARD  // timing-only build: reward skipped
-        RewardOut rw;
-        for (int k = 0; k < R6_NUM_TERMS; ++k) rw.terms[k] = 0.0f;
-        rw.sum = y[0] * p.alfa + c.thrust * p.beta + mass + v0;
-        rw.landed = false;
+            RewardOut rw;
+            for (int q = 0; q < R6_NUM_TERMS; ++q) rw.terms[q] = 0.0f;
+            rw.sum = y[0] * pr.alfa + c.thrust * pr.beta + mass + v0;
+            rw.landed = false;
 #else
-        const RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
+            const RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
 #endif
-        float rew = rw.sum + (bnd ? p.bounds_penalty : 0.0f);
-        if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
-        ep_step += 1u;
-        ep_ret += rew;
-        bool truncated = false;
-        if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
-            truncated = !done;
-            done = true;
+            landed = rw.landed;
+#pragma unroll
+            for (int q = 0; q < R6_NUM_TERMS; ++q) terms7[q] = rw.terms[q];
+            rew = rw.sum + (bnd ? pr.bounds_penalty : 0.0f);
+            if (pr.clip_reward) rew = fminf(fmaxf(rew, pr.clip_lo), pr.clip_hi);
+            ep_step += 1u;
+            ep_ret += rew;
+            if (pr.max_episode_steps > 0 && ep_step >= (uint32_t)pr.max_episode_steps) {
+                truncated = !done;
+                done = true;
+            }
         }
 
         // ---- outputs: reward, done, state rows, counters -----------------------------------------------
         if (live) {
             uniform_ptr(b.reward + e0)[lane] = rew;
             uniform_ptr(b.done + e0)[lane] = done ? 1 : 0;
-            if (b.flags)
-                uniform_ptr(b.flags + e0)[lane] = (uint8_t)((status ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
-                                                            (truncated ? R6_FLAG_TRUNCATED : 0));
             float* row = b.state + e0;
 #pragma unroll
             for (int j = 0; j < kDyn; ++j) {
@@ -234,12 +246,18 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
                 uniform_ptr(b.ep_step + e0)[lane] = ep_step;
                 uniform_ptr(b.ep_return + e0)[lane] = ep_ret;
             }
-            if (b.terms) {
-                float* trow = b.terms + e0;
+            if (opt_flags_terms) {   // optional outputs: their pointers are fetched only when present
+                const R6Buffers bo = load_buffers();
+                if (bo.flags)
+                    uniform_ptr(bo.flags + e0)[lane] = (uint8_t)((status ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
+                                                                 (truncated ? R6_FLAG_TRUNCATED : 0));
+                if (bo.terms) {
+                    float* trow = bo.terms + e0;
 #pragma unroll
-                for (int k = 0; k < R6_NUM_TERMS; ++k) {
-                    uniform_ptr(trow)[lane] = rw.terms[k];
-                    trow += ld;
+                    for (int q = 0; q < R6_NUM_TERMS; ++q) {
+                        uniform_ptr(trow)[lane] = terms7[q];
+                        trow += bo.ld;
+                    }
                 }
             }
         }
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
                 if (status) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
                 if (bnd) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
                 if (truncated) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
-                if (rw.landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
+                if (landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
             }
             if (p.auto_reset) {
                 const int64_t i = e0 + lane;
