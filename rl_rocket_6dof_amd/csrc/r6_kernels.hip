@@ -231,20 +231,24 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
             }
         }
 
-        // ---- outputs: reward, done, state rows, counters -----------------------------------------------
+        // ---- outputs: reward, done, state rows, counters (RK4: pointers re-read from kernarg, see above) --
         if (live) {
-            uniform_ptr(b.reward + e0)[lane] = rew;
-            uniform_ptr(b.done + e0)[lane] = done ? 1 : 0;
-            float* row = b.state + e0;
+            const R6Buffers bs = [&]() __attribute__((always_inline)) {
+                if constexpr (INTEG == R6_RK4) return load_buffers();
+                else return b;
+            }();
+            uniform_ptr(bs.reward + e0)[lane] = rew;
+            uniform_ptr(bs.done + e0)[lane] = done ? 1 : 0;
+            float* row = bs.state + e0;
 #pragma unroll
             for (int j = 0; j < kDyn; ++j) {
                 uniform_ptr(row)[lane] = y[j];
-                row += ld;
+                row += bs.ld;
             }
             uniform_ptr(row)[lane] = mass;
             if (has_ep) {
-                uniform_ptr(b.ep_step + e0)[lane] = ep_step;
-                uniform_ptr(b.ep_return + e0)[lane] = ep_ret;
+                uniform_ptr(bs.ep_step + e0)[lane] = ep_step;
+                uniform_ptr(bs.ep_return + e0)[lane] = ep_ret;
             }
             if (opt_flags_terms) {   // optional outputs: their pointers are fetched only when present
                 const R6Buffers bo = load_buffers();
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
         // ---- LDS tile -> contiguous 16 B-per-lane stores of the (64, OD) observation block ---------------
         wave_lds_sync();
         {
-            const gptr<float> dst = uniform_ptr(b.obs + e0 * OD);
+            const gptr<float> dst = uniform_ptr(((INTEG == R6_RK4) ? load_buffers().obs : b.obs) + e0 * OD);
             if constexpr (FULL) {
                 constexpr int n4 = 64 * OD / 4;
 #pragma unroll
