@@ -32,14 +32,16 @@
 extern "C" {
 #endif
 
-#define R6_ABI_VERSION 1
+#define R6_ABI_VERSION 2
 #define R6_STATE_DIM 14
 #define R6_ACTION_DIM 3
-#define R6_NUM_TERMS 7 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
-                          goal_conditions, final_position, final_velocity (rocket_env.py:353-359) */
+#define R6_NUM_TERMS 8 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
+                          goal_conditions, final_position, final_velocity (rocket_env.py:353-359),
+                          vertical_attitude_reward (wrappers.py:128-155, 0 unless enabled) */
 
 enum { R6_EULER = 0, R6_RK4 = 1 };
 enum { R6_SHAPING_ACCELERATION = 0, R6_SHAPING_VELOCITY = 1 };
+enum { R6_REWARD_STANDARD = 0, R6_REWARD_ANNEALED = 1 };
 /* bits of R6Buffers.flags[i] */
 enum { R6_FLAG_GROUND = 1, R6_FLAG_BOUNDS = 2, R6_FLAG_TRUNCATED = 4 };
 enum { R6_E_BADARG = -10001, R6_E_ALIGN = -10002 };
@@ -98,6 +100,14 @@ typedef struct R6Params {
     float clip_lo, clip_hi;
     int32_t max_episode_steps;  /* 0 = no TimeLimit (main_6DOF.py:31,47-50) */
     int32_t auto_reset;         /* 0/1 re-sample done envs in-kernel (VecEnv semantics) */
+    /* optional reward wrappers of the reference (my_environment/wrappers/wrappers.py) */
+    int32_t reward_mode;        /* R6_REWARD_ANNEALED = RewardAnnealing (:39-61): reward = attitude_constraint +
+                                   goal_conditions + final_position + final_velocity - xi * (action[2] + 1) */
+    float xi;                   /* reward_coeff["xi"] (default 0.01) */
+    int32_t vatt_enable;        /* 0/1 VerticalAttitudeReward (:128-155) */
+    float vatt_threshold;       /* threshold_height (1e-3) */
+    float vatt_weight;          /* weight (-0.5) */
+    int32_t reserved0;          /* keeps sizeof(R6Params) a multiple of 8 */
 } R6Params;
 
 /* Device buffers of one shard of n environments. */

@@ -9,7 +9,7 @@ import os
 
 from .params import R6Buffers, R6Params
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_reset",

@@ -26,7 +26,8 @@ from .params import (ACTION_DIM, MAX_BLOCKS, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUN
                      STAT_NAMES, R6Buffers, default_env_config, make_params)
 
 TERM_NAMES_ACC = ("atarg_tracking", "thrust_penalty", "eta", "attitude_constraint", "goal_conditions",
-                  "final_position", "final_velocity")          # rocket_env.py:342-359
+                  "final_position", "final_velocity",          # rocket_env.py:342-359
+                  "vertical_attitude_reward")                   # wrappers.py:141-147 (0 unless enabled)
 TERM_NAMES_VEL = ("vtarg_tracking",) + TERM_NAMES_ACC[1:]
 
 _EXPLICIT_RESET_BASE = 1 << 60   # keeps reset() draws disjoint from in-kernel auto-reset draws
@@ -102,7 +103,8 @@ class BatchedRocket6DOF:
                  remove_mass: bool = False, clip_reward=None, max_episode_steps: int = 0,
                  auto_reset: bool = True, seed: Optional[int] = None, env_offset: int = 0,
                  record_terms: bool = False, record_flags: bool = True, track_episodes: bool = True,
-                 numpy_io: bool = False, lib_path: Optional[str] = None):
+                 numpy_io: bool = False, lib_path: Optional[str] = None, reward_annealing: bool = False,
+                 vertical_attitude_reward=None):
         if num_envs < 1:
             raise ValueError("num_envs must be >= 1")
         self.lib = _lib.load(lib_path)   # raises if the HIP extension is missing -- no fallback
@@ -116,7 +118,7 @@ class BatchedRocket6DOF:
         self.params, self.spec = make_params(
             self.env_config, integrator=integrator, n_substeps=n_substeps, timestep=timestep,
             remove_mass=remove_mass, clip_reward=clip_reward, max_episode_steps=max_episode_steps,
-            auto_reset=auto_reset)
+            auto_reset=auto_reset, reward_annealing=reward_annealing, vertical_attitude_reward=vertical_attitude_reward)
         self.num_envs = int(num_envs)
         self.obs_dim = int(self.params.obs_dim)
         self.auto_reset = bool(auto_reset)
@@ -244,6 +246,27 @@ class BatchedRocket6DOF:
             rc = self.lib.r6_observe(C.byref(self.params), C.byref(self._buf), self._stream())
         _lib.check(rc, "r6_observe")
         return self._out(self.obs)
+
+    def terminal_errors(self) -> dict:
+        """Terminal-state errors of the envs that finished in the LAST step -- the quantities the
+        reference's montecarlo_script.py:33-51 writes per episode (position / velocity / attitude /
+        angular-velocity error and the terminal mass it labels "used mass").  Needs auto_reset (the
+        terminal observation is kept in ``final_obs``); device tensors, one entry per finished env."""
+        if self.final_obs is None:
+            raise RuntimeError("terminal_errors() needs auto_reset=True")
+        idx = self.done.nonzero(as_tuple=True)[0]
+        norm = torch.as_tensor(self.state_normalizer[: self.obs_dim], dtype=torch.float32, device=self.device)
+        st = self.final_obs[idx] * norm
+        out = {
+            "env_index": idx,
+            "final_position_error": st[:, 0:3].norm(dim=1),
+            "final_velocity_error": st[:, 3:6].norm(dim=1),
+            "attitude_error": 0.5 * torch.rad2deg(torch.acos(st[:, 6].clamp(-1, 1))),
+            "angular_velocity_error": st[:, 10:13].norm(dim=1),
+        }
+        if self.obs_dim == 14:
+            out["used mass"] = st[:, 13]
+        return out
 
     def episode_stats(self, clear: bool = True) -> dict:
         """Sums over the episodes finished since the last clear (per-workgroup partials reduced in

@@ -502,9 +502,39 @@ __device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[
     o.terms[4] = landed ? p.kappa : 0.0f;                             // env:399
     o.terms[5] = fmaxf(p.max_r_f - rn, 0.0f) * p.w_r_f;               // env:400
     o.terms[6] = (rn < p.max_r_f && zero_h) ? fmaxf(p.max_v_f - vn, 0.0f) * p.w_v_f : 0.0f;  // env:401
+    o.terms[7] = 0.0f;
     o.landed = landed;
     o.sum = ((((((o.terms[0] + o.terms[1]) + o.terms[2]) + o.terms[3]) + o.terms[4]) + o.terms[5]) + o.terms[6]);
     return o;
+}
+
+// Total step reward from the 7 terms: env:228-229 (bounds penalty) and the reference's optional reward
+// wrappers (my_environment/wrappers/wrappers.py).  `a2n` is the normalised throttle action, `q0` / `x` the
+// post-step attitude scalar and height.  May rewrite terms[] (annealed mode, vertical-attitude term).
+__device__ __forceinline__ float finalize_reward(const R6Params& p, RewardOut& rw, bool bnd, float a2n, const float (&y)[kDyn]) {
+    const float x = y[0], q0 = y[6];
+    float r;
+    if (p.reward_mode == R6_REWARD_ANNEALED) {
+        // RewardAnnealing (wrappers.py:39-61): the env reward is discarded (bounds penalty included) and
+        // rebuilt from four terms plus a new thrust penalty -xi * (action[2] + 1)
+        const float tpen = -p.xi * (a2n + 1.0f);
+        rw.terms[0] = 0.0f;
+        rw.terms[1] = tpen;
+        rw.terms[2] = 0.0f;
+        r = (((rw.terms[3] + rw.terms[4]) + rw.terms[5]) + rw.terms[6]) + tpen;
+    } else {
+        r = rw.sum + (bnd ? p.bounds_penalty : 0.0f);
+    }
+    if (p.vatt_enable && x < p.vatt_threshold && rw.terms[6] > 0.0f) {
+        // VerticalAttitudeReward (wrappers.py:128-155): clip(2 * degrees(acos(q0)) * weight, -10, 10).
+        // acos(q0) of the unit quaternion is taken as atan2(|q_v|, q0): near upright (q0 -> 1) acos is
+        // ill-conditioned in fp32 (3e-5 relative at 2.6 deg), the vector part carries the angle exactly.
+        const float qv = sqrtf(fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
+        const float va = fminf(fmaxf(2.0f * 57.29577951308232f * atan2f(qv, q0) * p.vatt_weight, -10.0f), 10.0f);
+        rw.terms[7] = va;
+        r += va;
+    }
+    return r;
 }
 
 // env:591-593 -- inclusive float32 box; NaN counts as a violation (Box.contains is False).

@@ -216,12 +216,12 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
             rw.sum = y[0] * pr.alfa + c.thrust * pr.beta + mass + v0;
             rw.landed = false;
 #else
-            const RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
+            RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
 #endif
             landed = rw.landed;
+            rew = finalize_reward(pr, rw, bnd, a2, y);
 #pragma unroll
             for (int q = 0; q < R6_NUM_TERMS; ++q) terms7[q] = rw.terms[q];
-            rew = rw.sum + (bnd ? pr.bounds_penalty : 0.0f);
             if (pr.clip_reward) rew = fminf(fmaxf(rew, pr.clip_lo), pr.clip_hi);
             ep_step += 1u;
             ep_ret += rew;

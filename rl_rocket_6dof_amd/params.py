@@ -18,7 +18,7 @@ import yaml
 
 STATE_DIM = 14
 ACTION_DIM = 3
-NUM_TERMS = 7
+NUM_TERMS = 8
 NUM_STATS = 8
 BLOCK = 256
 MAX_BLOCKS = 16384
@@ -52,6 +52,8 @@ class R6Params(C.Structure):
         ("ic_lo", C.c_float * STATE_DIM), ("ic_range", C.c_float * STATE_DIM),
         ("obs_dim", C.c_int32), ("clip_reward", C.c_int32), ("clip_lo", C.c_float), ("clip_hi", C.c_float),
         ("max_episode_steps", C.c_int32), ("auto_reset", C.c_int32),
+        ("reward_mode", C.c_int32), ("xi", C.c_float), ("vatt_enable", C.c_int32), ("vatt_threshold", C.c_float),
+        ("vatt_weight", C.c_float), ("reserved0", C.c_int32),
     ]
 
 
@@ -153,8 +155,10 @@ def auto_substeps(dt: float) -> int:
 
 def make_params(env_config: dict, *, integrator: str = "rk4", n_substeps: Optional[int] = None,
                 timestep: Optional[float] = None, remove_mass: bool = False, clip_reward=None,
-                max_episode_steps: int = 0, auto_reset: bool = True):
-    """Returns (R6Params, EnvSpec)."""
+                max_episode_steps: int = 0, auto_reset: bool = True, reward_annealing: bool = False,
+                vertical_attitude_reward=None):
+    """Returns (R6Params, EnvSpec).  ``reward_annealing``: RewardAnnealing wrapper (wrappers.py:39-61);
+    ``vertical_attitude_reward``: None or (threshold_height, weight) of VerticalAttitudeReward (:128-155)."""
     spec = derive_spec(env_config)
     dt = float(spec.timestep if timestep is None else timestep)
     p = R6Params()
@@ -190,4 +194,10 @@ def make_params(env_config: dict, *, integrator: str = "rk4", n_substeps: Option
         p.clip_reward, p.clip_lo, p.clip_hi = 1, float(clip_reward[0]), float(clip_reward[1])
     p.max_episode_steps = int(max_episode_steps)
     p.auto_reset = 1 if auto_reset else 0
+    p.reward_mode = 1 if reward_annealing else 0
+    p.xi = float(c.get("xi", 0.01))                       # wrappers.py:42
+    if vertical_attitude_reward is None:
+        p.vatt_enable, p.vatt_threshold, p.vatt_weight = 0, 1e-3, -0.5
+    else:
+        p.vatt_enable, p.vatt_threshold, p.vatt_weight = 1, float(vertical_attitude_reward[0]), float(vertical_attitude_reward[1])
     return p, spec

@@ -62,12 +62,55 @@ class _Env:
         return None
 
 
+class _Wrapper(_Env):
+    """gym-0.21 ``Wrapper``: forwards unknown attributes to the wrapped env."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self, **kw):
+        return self.env.reset(**kw)
+
+
+class _ObservationWrapper(_Wrapper):
+    def reset(self, **kw):
+        return self.observation(self.env.reset(**kw))
+
+    def step(self, action):
+        o, r, d, i = self.env.step(action)
+        return self.observation(o), r, d, i
+
+
+class _RewardWrapper(_Wrapper):
+    def step(self, action):
+        o, r, d, i = self.env.step(action)
+        return o, self.reward(r), d, i
+
+
 def _install_stubs():
     gym = types.ModuleType("gym")
     spaces = types.ModuleType("gym.spaces")
     spaces.Box = _Box
     gym.Env = _Env
+    _Env.unwrapped = property(lambda self: self)
+    gym.Wrapper, gym.ObservationWrapper, gym.RewardWrapper = _Wrapper, _ObservationWrapper, _RewardWrapper
     gym.spaces = spaces
+    wandb = types.ModuleType("wandb")
+    wandb.run = None
+    wandb.log = lambda *a, **k: None
+    sys.modules.setdefault("wandb", wandb)
     sys.modules.setdefault("gym", gym)
     sys.modules.setdefault("gym.spaces", spaces)
     pv = types.ModuleType("pyvista")
@@ -102,3 +145,16 @@ def load_reference():
     with open(os.path.join(REF_ROOT, "config.yaml")) as f:
         cfg = yaml.safe_load(f)
     return sim.Simulator6DOF, env.Rocket6DOF, cfg["env_config"]
+
+
+def load_reference_wrappers():
+    """The reference's reward wrappers (my_environment/wrappers/wrappers.py), executed where they lie."""
+    load_reference()
+    try:
+        import matplotlib  # noqa: F401  (wrappers.py imports pyplot at module top)
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules.setdefault("matplotlib", mpl)
+        sys.modules.setdefault("matplotlib.pyplot", mpl.pyplot)
+    return _load("my_environment.wrappers.wrappers", "my_environment/wrappers/wrappers.py")

@@ -17,6 +17,8 @@ What each file pins (reference file:line):
                    (rocket_env.py:317-402, :591-593) on crafted post-states
   g6_fixed_step    reference RHS driven by textbook Euler / RK4 (the reference has no fixed-step
                    integrator; this is the parity oracle for BASELINE configs 2-3)
+  g7_wrappers      RewardAnnealing / VerticalAttitudeReward (my_environment/wrappers/wrappers.py:39-61,
+                   :128-155) around the reference env   (python generate_golden.py --only g7)
 """
 from __future__ import annotations
 
@@ -133,7 +135,64 @@ def _pack(recs_by_ep):
     return out
 
 
+def gen_g7():
+    from _ref_loader import load_reference_wrappers
+
+    Sim, Env, cfg = load_reference()
+    W = load_reference_wrappers()
+    sim_module = sys.modules["my_environment.utils.simulator"]
+    spy = _IvpSpy(sim_module)
+    rng = np.random.RandomState(7)
+    out = {}
+    for name in ("annealing", "vertical", "both"):
+        base = Env(**cfg)
+        if name == "annealing":
+            env = W.RewardAnnealing(base)
+        elif name == "vertical":
+            env = W.VerticalAttitudeReward(base)
+        else:
+            env = W.VerticalAttitudeReward(W.RewardAnnealing(base))
+        rec = dict(pre=[], m0=[], action=[], reward=[], done=[], terms=[], vatt=[], tpen=[])
+        for k in range(60):
+            icv = np.zeros(14)
+            icv[0] = rng.uniform(0.3, 8.0)
+            icv[1:3] = rng.uniform(-25, 25, 2)
+            icv[3] = rng.uniform(-12, -1)
+            icv[4:6] = rng.uniform(-3, 3, 2)
+            tilt = rng.uniform(0, 0.6)
+            icv[6:10] = _quat_from_axis_angle([0.0, rng.normal(), rng.normal() + 1e-9], tilt)
+            icv[10:13] = rng.uniform(-0.2, 0.2, 3)
+            icv[13] = rng.uniform(30e3, 41e3)
+            orig = base.init_space.sample
+            base.init_space.sample = lambda: np.array(icv, dtype=np.float32)
+            env.reset()
+            base.init_space.sample = orig
+            for j in range(40):
+                pre = np.array(base.SIM.state, dtype=np.float64)
+                a = rng.uniform(-1, 1, 3).astype(np.float32)
+                a[2] = rng.uniform(-0.8, 0.2)
+                obs, rew, done, info = env.step(a)
+                rd = info["rewards_dict"]
+                rec["pre"].append(pre)
+                rec["m0"].append(float(base.SIM.m))
+                rec["action"].append(a)
+                rec["reward"].append(float(rew))
+                rec["done"].append(bool(done))
+                rec["terms"].append([float(rd.get(t, 0.0)) for t in TERMS])
+                rec["vatt"].append(float(rd.get("vertical_attitude_reward", 0.0)))
+                rec["tpen"].append(float(rd.get("thrust_penalty", 0.0)))
+                if done:
+                    break
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = np.array(v)
+        print("G7", name, "steps", len(rec["reward"]), "vatt!=0", int((np.array(rec["vatt"]) != 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "g7_wrappers.npz"), config=np.array(json.dumps(cfg)), meta=_meta(), **out)
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g7":
+        gen_g7()
+        return
     Sim, Env, cfg = load_reference()
     sim_module = sys.modules["my_environment.utils.simulator"]
     spy = _IvpSpy(sim_module)

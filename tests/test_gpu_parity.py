@@ -65,7 +65,7 @@ def _check_against_golden(env, obs, rew, done, G, P, what):
     post = env.get_state().cpu().numpy()
     e_state = assert_close_scaled(post, G["post"], P.normalizer[None, :], RTOL, f"{what}: post-state")
     e_obs = assert_close_scaled(obs, G["obs"], 1.0, RTOL, f"{what}: observation")
-    terms = env.terms[:, : env.num_envs].t().cpu().numpy()
+    terms = env.terms[:7, : env.num_envs].t().cpu().numpy()
     e_terms = assert_close_scaled(terms, G["terms"], TERM_SCALE, RTOL, f"{what}: reward terms")
     e_rew = assert_close_scaled(rew, G["reward"], REWARD_SCALE, RTOL, f"{what}: reward")
     print(f"[{what}] n={len(rew)} worst scaled err: state {e_state:.2e} obs {e_obs:.2e} terms {e_terms:.2e} reward {e_rew:.2e}")
@@ -141,7 +141,7 @@ def test_g5_reward_known_answers(torch_cuda, cfg, P):
     torch.cuda.synchronize()
     flags = env.flags.cpu().numpy()
     np.testing.assert_array_equal((flags & 2) >> 1, g5["bounds"], err_msg="bounds flag")
-    terms = env.terms[:, :n].t().cpu().numpy()
+    terms = env.terms[:7, :n].t().cpu().numpy()
     # discrete terms (attitude, goal) must agree exactly in which cases fire
     np.testing.assert_array_equal(terms[:, 3] != 0, g5["terms"][:, 3] != 0, err_msg="attitude_constraint cases")
     np.testing.assert_array_equal(terms[:, 4] != 0, g5["terms"][:, 4] != 0, err_msg="goal_conditions cases")
@@ -256,7 +256,7 @@ def test_velocity_shaping_vs_oracle(torch_cuda, cfg):
     env = BatchedRocket6DOF(n, vcfg, auto_reset=False, record_terms=True)
     env.set_state(pre.astype(np.float32), m0=m0.astype(np.float32), v0=v0.astype(np.float32))
     obs, rew, done, _ = env.step(torch.as_tensor(act, device=env.device))
-    terms = env.terms[:, :n].t().cpu().numpy()
+    terms = env.terms[:7, :n].t().cpu().numpy()
     Pv = onp.OracleParams.from_config(vcfg)
     for i in range(n):
         o = onp.env_step(pre[i].astype(np.float32).astype(np.float64), float(np.float32(m0[i])), act[i], Pv, "rk4",
@@ -378,3 +378,49 @@ def test_single_env_surface(torch_cuda, cfg):
         total += rew
     assert done and len(env.SIM.states) == ep0.sum() + 1 and env.SIM.t == round(0.1 * ep0.sum(), 3)
     env.close()
+
+
+@pytest.mark.parametrize("name,kw", [("annealing", dict(reward_annealing=True)),
+                                     ("vertical", dict(vertical_attitude_reward=(1e-3, -0.5))),
+                                     ("both", dict(reward_annealing=True, vertical_attitude_reward=(1e-3, -0.5)))])
+def test_g7_reward_wrappers_vs_reference(torch_cuda, cfg, name, kw):
+    """RewardAnnealing / VerticalAttitudeReward (my_environment/wrappers/wrappers.py:39-61, :128-155) as
+    fused kernel modes, against the reference wrappers run around the reference env."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    g7 = load_golden("g7_wrappers.npz")
+    pre, m0, act = g7[f"{name}_pre"], g7[f"{name}_m0"], g7[f"{name}_action"]
+    n = len(pre)
+    env = BatchedRocket6DOF(n, cfg, auto_reset=False, record_terms=True, **kw)
+    env.set_state(pre.astype(np.float32), m0=m0.astype(np.float32))
+    obs, rew, done, infos = env.step(torch.as_tensor(act, device=env.device))
+    np.testing.assert_array_equal(done.cpu().numpy(), g7[f"{name}_done"])
+    assert_close_scaled(rew.cpu().numpy(), g7[f"{name}_reward"], REWARD_SCALE, RTOL, f"G7 {name} reward")
+    terms = env.terms[:, :n].t().cpu().numpy()
+    np.testing.assert_array_equal(terms[:, 7] != 0, g7[f"{name}_vatt"] != 0)
+    assert_close_scaled(terms[:, 7], g7[f"{name}_vatt"], 1.0, RTOL, f"G7 {name} vertical attitude term")
+    if "reward_annealing" in kw:
+        assert_close_scaled(terms[:, 1], g7[f"{name}_tpen"], 1e-2, RTOL, f"G7 {name} thrust penalty")
+        assert infos[0]["rewards_dict"]["eta"] == 0.0 and "vertical_attitude_reward" in infos[0]
+
+
+def test_terminal_errors_montecarlo(torch_cuda, cfg):
+    """montecarlo_script.py:33-51 statistics from the terminal observations of finished envs."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    G = load_golden("g4_ground_events.npz")
+    last = np.nonzero(G["done"] == 1)[0]
+    n = len(last)
+    env = BatchedRocket6DOF(n, cfg, auto_reset=True, seed=1)
+    env.set_state(G["pre"][last].astype(np.float32), m0=G["m0"][last].astype(np.float32))
+    env.step(torch.as_tensor(G["action"][last], device=env.device))
+    te = env.terminal_errors()
+    assert len(te["env_index"]) == n
+    post = G["post"][last]
+    assert_close_scaled(te["final_position_error"].cpu().numpy(), np.linalg.norm(post[:, 0:3], axis=1), 1.0, 1e-5, "position error")
+    assert_close_scaled(te["final_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 3:6], axis=1), 1.0, 1e-5, "velocity error")
+    assert_close_scaled(te["attitude_error"].cpu().numpy(), 0.5 * np.rad2deg(np.arccos(post[:, 6])), 1.0, 1e-4, "attitude error")
+    assert_close_scaled(te["angular_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 10:13], axis=1), 0.1, 1e-5, "omega error")
+    assert_close_scaled(te["used mass"].cpu().numpy(), post[:, 13], 1.0, 1e-5, "terminal mass")

@@ -182,3 +182,26 @@ def test_reset_sample_distribution(P):
     # distinct streams per env and per step index
     assert not np.array_equal(onp.reset_sample(42, 1, 0, P), onp.reset_sample(42, 2, 0, P))
     assert not np.array_equal(onp.reset_sample(42, 1, 0, P), onp.reset_sample(42, 1, 1, P))
+
+
+def test_g7_reward_wrappers(P):
+    """RewardAnnealing / VerticalAttitudeReward (wrappers.py:39-61, :128-155) restated in
+    oracle_np.apply_reward_wrappers, against the reference wrappers run around the reference env."""
+    from conftest import load_golden
+
+    g7 = load_golden("g7_wrappers.npz")
+    for name, kw in (("annealing", dict(annealing=True)), ("vertical", dict(vertical_attitude=(1e-3, -0.5))),
+                     ("both", dict(annealing=True, vertical_attitude=(1e-3, -0.5)))):
+        pre, m0, act = g7[f"{name}_pre"], g7[f"{name}_m0"], g7[f"{name}_action"]
+        n_v = 0
+        for i in range(0, len(pre), 2):
+            o = onp.env_step(pre[i], float(m0[i]), act[i], P, "adaptive")
+            rew, t8 = onp.apply_reward_wrappers(o["reward"], o["terms"], act[i], o["post"], P, **kw)
+            assert o["done"] == bool(g7[f"{name}_done"][i])
+            assert_close_scaled(rew, g7[f"{name}_reward"][i], 1.0, 5e-6, f"G7 {name} reward {i}")
+            assert_close_scaled(t8[7], g7[f"{name}_vatt"][i], 1.0, 5e-6, f"G7 {name} vertical attitude term {i}")
+            if "annealing" in kw:
+                assert_close_scaled(t8[1], g7[f"{name}_tpen"][i], 1e-2, 1e-6, f"G7 {name} thrust penalty {i}")
+            n_v += t8[7] != 0
+        if "vertical_attitude" in kw:
+            assert n_v > 10
