@@ -39,7 +39,7 @@ extern "C" {
                           goal_conditions, final_position, final_velocity (rocket_env.py:353-359),
                           vertical_attitude_reward (wrappers.py:128-155, 0 unless enabled) */
 
-enum { R6_EULER = 0, R6_RK4 = 1 };
+enum { R6_EULER = 0, R6_RK4 = 1, R6_RK45 = 2 /* adaptive Dormand-Prince, scipy solve_ivp step control */ };
 enum { R6_SHAPING_ACCELERATION = 0, R6_SHAPING_VELOCITY = 1 };
 enum { R6_REWARD_STANDARD = 0, R6_REWARD_ANNEALED = 1 };
 /* bits of R6Buffers.flags[i] */
@@ -65,8 +65,8 @@ enum {
 typedef struct R6Params {
     /* integrator */
     float dt;             /* env timestep [s] (config.yaml timestep) */
-    int32_t integrator;   /* R6_EULER | R6_RK4 */
-    int32_t n_substeps;   /* >= 1 fixed sub-steps per env step */
+    int32_t integrator;   /* R6_EULER | R6_RK4 | R6_RK45 */
+    int32_t n_substeps;   /* >= 1 fixed sub-steps per env step (ignored by R6_RK45) */
     int32_t shaping;      /* R6_SHAPING_* (reward_shaping_type) */
     /* action scaling, rocket_env.py:86-87, :509-521 */
     float max_gimbal;     /* rad */
@@ -130,6 +130,7 @@ typedef struct R6Buffers {
     float *ep_return;     /* [n]       in/out: running episode return (Monitor) */
     float *fin_return;    /* [n]       out at done: episode return */
     uint32_t *fin_length; /* [n]       out at done: episode length */
+    uint8_t *nfev;        /* [n]       out: RHS evaluations of the step (scipy sol.nfev), saturating at 255 */
     float *stats;         /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out: per-workgroup running sums over
                                        finished episodes (see R6_STAT_*); no float atomics; the
                                        caller sums the rows */

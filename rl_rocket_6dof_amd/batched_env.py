@@ -104,7 +104,7 @@ class BatchedRocket6DOF:
                  auto_reset: bool = True, seed: Optional[int] = None, env_offset: int = 0,
                  record_terms: bool = False, record_flags: bool = True, track_episodes: bool = True,
                  numpy_io: bool = False, lib_path: Optional[str] = None, reward_annealing: bool = False,
-                 vertical_attitude_reward=None):
+                 vertical_attitude_reward=None, record_nfev: bool = False):
         if num_envs < 1:
             raise ValueError("num_envs must be >= 1")
         self.lib = _lib.load(lib_path)   # raises if the HIP extension is missing -- no fallback
@@ -145,6 +145,7 @@ class BatchedRocket6DOF:
         self.done = torch.zeros((n,), dtype=torch.uint8, device=dev)
         self.flags = torch.zeros((n,), dtype=torch.uint8, device=dev) if record_flags else None
         self.terms = torch.zeros((NUM_TERMS, ld), **f32) if record_terms else None
+        self.nfev = torch.zeros((n,), dtype=torch.uint8, device=dev) if record_nfev else None
         self.final_obs = torch.zeros((n, self.obs_dim), **f32) if auto_reset else None
         track = bool(track_episodes or max_episode_steps)
         self.ep_step = torch.zeros((n,), dtype=torch.int32, device=dev) if track else None
@@ -169,6 +170,7 @@ class BatchedRocket6DOF:
         b.flags, b.terms, b.final_obs = _ptr(self.flags), _ptr(self.terms), _ptr(self.final_obs)
         b.ep_step, b.ep_return = _ptr(self.ep_step), _ptr(self.ep_return)
         b.fin_return, b.fin_length, b.stats = _ptr(self.fin_return), _ptr(self.fin_length), _ptr(self.stats)
+        b.nfev = _ptr(self.nfev)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -306,6 +308,6 @@ class BatchedRocket6DOF:
         raise NotImplementedError("rendering (pyvista) is outside the hot path and not provided")
 
     def __repr__(self):
-        integ = "rk4" if self.params.integrator == 1 else "euler"
+        integ = {0: "euler", 1: "rk4", 2: "rk45"}[self.params.integrator]
         return (f"BatchedRocket6DOF(num_envs={self.num_envs}, {integ}, dt={self.timestep}, "
                 f"substeps={self.params.n_substeps}, obs_dim={self.obs_dim}, device={self.device})")

@@ -325,6 +325,187 @@ __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Co
     return status;
 }
 
+// ---- adaptive Dormand-Prince RK45 with scipy's step control (sim:83-88 = scipy.integrate.solve_ivp
+//      defaults: RK45, rtol 1e-3, atol 1e-6, first_step None, terminal event on x) ----------------------
+// The algorithmic twin of the reference's integrator, per lane: initial step by Hairer's rule
+// (scipy _ivp/common.py select_initial_step), error norm = RMS of err / (atol + rtol max(|y|,|y_new|))
+// over all 14 components, accept if < 1, factor = min(10, 0.9 err^-1/5) (min(1, .) after a rejection),
+// else shrink by max(0.2, 0.9 err^-1/5) (scipy _ivp/rk.py _step_impl); the terminal event is located
+// on the method's quartic dense output (rk.py RkDenseOutput, P matrix) and the state taken from it.
+// Tableau: Dormand & Prince 1980; dense output: Shampine 1986 (values as tabulated in scipy 1.15.3).
+// Mass has a constant derivative: it is advanced analytically (its error estimate is exactly 0,
+// sum(E) = 0) but is counted in the norms like scipy counts it.
+namespace dp45 {
+constexpr int S = 7;  // 6 stages + f(y_new)
+constexpr float C[6] = {0.0f, 0.2f, 0.3f, 0.8f, (float)(8.0 / 9.0), 1.0f};
+constexpr float A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {(float)0.2, 0, 0, 0, 0},
+    {(float)0.075, (float)0.225, 0, 0, 0},
+    {(float)0.97777777777777775, (float)-3.7333333333333334, (float)3.5555555555555554, 0, 0},
+    {(float)2.9525986892242035, (float)-11.595793324188385, (float)9.8228928516994358, (float)-0.29080932784636487, 0},
+    {(float)2.8462752525252526, (float)-10.757575757575758, (float)8.9064227177434727, (float)0.27840909090909088,
+     (float)-0.2735313036020583}};
+constexpr float B[6] = {(float)0.091145833333333329, 0.0f, (float)0.44923629829290207, (float)0.65104166666666663,
+                        (float)-0.322376179245283, (float)0.13095238095238096};
+constexpr float E[7] = {(float)-0.0012326388888888888, 0.0f, (float)0.0042527702905061394, (float)-0.036979166666666667,
+                        (float)0.05086379716981132, (float)-0.041904761904761903, 0.025f};
+constexpr float P[7][4] = {{1.0f, (float)-2.8535800653862835, (float)3.0717434641059005, (float)-1.1270175653862835},
+                           {0, 0, 0, 0},
+                           {0, (float)4.0231333792303046, (float)-6.2493215652889997, (float)2.675424484351598},
+                           {0, (float)-3.7324019615885042, (float)10.068970589843675, (float)-5.6855269615885042},
+                           {0, (float)2.5548038301849423, (float)-6.3991123773510168, (float)3.5219323679207912},
+                           {0, (float)-1.3744241142186024, (float)3.2726577522467291, (float)-1.7672812570757455},
+                           {0, (float)1.3824689317781436, (float)-3.7649378635562871, (float)2.3824689317781438}};
+constexpr float kRtol = 1e-3f, kAtol = 1e-6f;
+constexpr float kSafety = 0.9f, kMinFactor = 0.2f, kMaxFactor = 10.0f;
+}  // namespace dp45
+
+// One env step [0, dt] of the adaptive integrator.  Returns status (0 reached dt, 1 ground event,
+// -1 step size underflow -- the reference folds any non-zero status into done, env:213).
+// nfev receives the number of RHS evaluations (scipy's sol.nfev).
+__device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J, float dt,
+                                              int& nfev) {
+    using namespace dp45;
+    float K[S][kDyn];
+    float ynew[kDyn];
+    const float mdot = c.mdot;
+    auto sq = [](float v) { return v * v; };
+
+    rhs13(y, frcp(mass), c, J, K[0]);
+    nfev = 1;
+    // ---- select_initial_step (common.py) --------------------------------------------------------------
+    float h_abs;
+    {
+        float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) {
+            const float isc = frcp(fmaf(fabsf(y[i]), kRtol, kAtol));
+            d0 += sq(y[i] * isc);
+            d1 += sq(K[0][i] * isc);
+        }
+        const float iscm = frcp(fmaf(fabsf(mass), kRtol, kAtol));
+        d0 = sqrtf((d0 + sq(mass * iscm)) * (1.0f / 14.0f));
+        d1 = sqrtf((d1 + sq(mdot * iscm)) * (1.0f / 14.0f));
+        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        h0 = fminf(h0, dt);
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) ynew[i] = fmaf(h0, K[0][i], y[i]);
+        rhs13(ynew, frcp(fmaf(-mdot, h0, mass)), c, J, K[1]);
+        nfev = 2;
+        float d2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) d2 += sq((K[1][i] - K[0][i]) * frcp(fmaf(fabsf(y[i]), kRtol, kAtol)));
+        d2 = sqrtf(d2 * (1.0f / 14.0f)) / h0;
+        const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+        h_abs = fminf(fminf(100.0f * h0, h1), dt);
+    }
+
+    float t = 0.0f;
+    int status = 0;
+#pragma unroll 1
+    for (int guard = 0; guard < 4096 && status == 0 && t < dt; ++guard) {
+        const float min_step = 1e-6f * dt;   // fp32 stand-in for scipy's 10 ulp(t)
+        h_abs = fmaxf(h_abs, min_step);
+        bool rejected = false, accepted = false;
+        float h = 0.0f;
+#pragma unroll 1
+        for (int tries = 0; tries < 64 && !accepted; ++tries) {
+            if (h_abs < min_step) {
+                status = -1;
+                break;
+            }
+            h = fminf(h_abs, dt - t);
+            h_abs = h;
+            // ---- rk_step (rk.py): stages 1..5, y_new, f_new --------------------------------------------
+#pragma unroll
+            for (int st = 1; st < 6; ++st) {
+                float ys[kDyn];
+#pragma unroll
+                for (int i = 0; i < kDyn; ++i) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < st; ++j) acc = fmaf(A[st][j], K[j][i], acc);
+                    ys[i] = fmaf(h, acc, y[i]);
+                }
+                rhs13(ys, frcp(fmaf(-mdot, t + C[st] * h, mass)), c, J, K[st]);
+            }
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = fmaf(B[j], K[j][i], acc);
+                ynew[i] = fmaf(h, acc, y[i]);
+            }
+            rhs13(ynew, frcp(fmaf(-mdot, t + h, mass)), c, J, K[6]);
+            nfev += 6;
+            // ---- error norm ------------------------------------------------------------------------------
+            float en = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                float e = 0.0f;
+#pragma unroll
+                for (int j = 0; j < S; ++j) e = fmaf(E[j], K[j][i], e);
+                const float sc = fmaf(fmaxf(fabsf(y[i]), fabsf(ynew[i])), kRtol, kAtol);
+                en += sq(e * h / sc);
+            }
+            en = sqrtf(en * (1.0f / 14.0f));   // the mass component contributes 0 to the sum, 1 to the count
+            if (en < 1.0f) {
+                float factor = (en == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * powf(en, -0.2f));
+                if (rejected) factor = fminf(1.0f, factor);
+                h_abs *= factor;
+                accepted = true;
+            } else {
+                h_abs *= fmaxf(kMinFactor, kSafety * powf(en, -0.2f));
+                rejected = true;
+            }
+        }
+        if (!accepted) {
+            if (status == 0) status = -1;
+            break;
+        }
+        // ---- terminal event on the accepted sub-step (ivp.py find_active_events / handle_events) ---------
+        if (crossing(y[0], ynew[0])) {
+            // x(s) = x_old + h (Q0 s + Q1 s^2 + Q2 s^3 + Q3 s^4), Q = K^T P
+            float q[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) q[m] = fmaf(K[j][0], P[j][m], q[m]);
+            }
+            const float cx[5] = {y[0], h * q[0], h * q[1], h * q[2], h * q[3]};
+            const float th = poly_root01(cx, y[0], ynew[0]);
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                float qq[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) qq[m] = fmaf(K[j][i], P[j][m], qq[m]);
+                }
+                y[i] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[i]);
+            }
+            t += th * h;
+            status = 1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                y[i] = ynew[i];
+                K[0][i] = K[6][i];   // FSAL
+            }
+            t += h;
+        }
+    }
+    mass = fmaf(-mdot, t, mass);
+    const float n2 = fmaf(y[6], y[6], fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
+    const float inv = frsq(n2);
+    y[6] *= inv;
+    y[7] *= inv;
+    y[8] *= inv;
+    y[9] *= inv;
+    return status;
+}
+
 // ---- reward (env:317-402) ------------------------------------------------------------------------
 
 // env:528-546 -- t_go = largest positive real root of  g^2 t^4 + c2 t^2 + c1 t + c0,

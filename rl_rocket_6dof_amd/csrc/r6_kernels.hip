@@ -139,7 +139,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
 template <int INTEG, int SHAPING, int OD>
-__global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
+__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
     const int64_t nw = (int64_t)gridDim.x * kWaves;
     const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
-    const bool opt_flags_terms = b.flags != nullptr || b.terms != nullptr;
+    const bool opt_flags_terms = b.flags != nullptr || b.terms != nullptr || b.nfev != nullptr;
 
     if (tid == 0) rq_count = 0;
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
@@ -192,7 +192,14 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
         asm volatile("" :: "v"(c.tbx), "v"(c.tby), "v"(c.tbz), "v"(J.inv_jt), "v"(J.jdiff));
         y[3] += p.dt * c.mdot;
 #else
-        const int status = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
+        int nfev = 0;
+        int status;
+        if constexpr (INTEG == R6_RK45) {
+            status = integrate_rk45(y, mass, c, J, p.dt, nfev);
+        } else {
+            status = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
+            nfev = (INTEG == R6_RK4 ? 4 : 1) * p.n_substeps;
+        }
 #endif
 
         // ---- termination (env:213, :591-593), reward (env:215, :228-229, :317-402),
@@ -253,8 +260,9 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
             if (opt_flags_terms) {   // optional outputs: their pointers are fetched only when present
                 const R6Buffers bo = load_buffers();
                 if (bo.flags)
-                    uniform_ptr(bo.flags + e0)[lane] = (uint8_t)((status ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
+                    uniform_ptr(bo.flags + e0)[lane] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
                                                                  (truncated ? R6_FLAG_TRUNCATED : 0));
+                if (bo.nfev) uniform_ptr(bo.nfev + e0)[lane] = (uint8_t)(nfev > 255 ? 255 : nfev);
                 if (bo.terms) {
                     float* trow = bo.terms + e0;
 #pragma unroll
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(kBlock, 5) void step_kernel(const R6Params p, const
                 atomicAdd(&blk_stats[R6_STAT_RETURN], ep_ret);
                 atomicAdd(&blk_stats[R6_STAT_RETURN_SQ], ep_ret * ep_ret);
                 atomicAdd(&blk_stats[R6_STAT_LENGTH], (float)ep_step);
-                if (status) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
+                if (status == 1) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
                 if (bnd) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
                 if (truncated) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
                 if (landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
@@ -398,11 +406,13 @@ __global__ __launch_bounds__(kBlock) void sim_step_kernel(const R6Params p, floa
     float mass = state[13 * ld + i];
     const Control c = make_control_physical(u[3 * i + 0], u[3 * i + 1], u[3 * i + 2]);
     const Inertia J = make_inertia(epconst[i]);
-    const int st = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
+    int st, nfev = 0;
+    if constexpr (INTEG == R6_RK45) st = integrate_rk45(y, mass, c, J, p.dt, nfev);
+    else st = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
 #pragma unroll
     for (int j = 0; j < kDyn; ++j) state[j * ld + i] = y[j];
     state[13 * ld + i] = mass;
-    if (status) status[i] = (uint8_t)st;
+    if (status) status[i] = (uint8_t)(st == 1 ? 1 : (st != 0 ? 255 : 0));   // 255 = solver failure (scipy status -1)
 }
 
 __global__ __launch_bounds__(kBlock) void rhs_kernel(const float* ys, const float* epconst, const float* u, float* dys,
@@ -451,7 +461,7 @@ int validate_common(const R6Params* p, const R6Buffers* b) {
     if (b->n < 0 || b->ld < b->n) return fail(R6_E_BADARG, "need 0 <= n <= ld");
     if (b->n >= (int64_t)1 << 31) return fail(R6_E_BADARG, "n must be < 2^31 per shard");
     if (p->obs_dim != 13 && p->obs_dim != 14) return fail(R6_E_BADARG, "obs_dim must be 13 or 14");
-    if (p->integrator != R6_EULER && p->integrator != R6_RK4) return fail(R6_E_BADARG, "bad integrator");
+    if (p->integrator != R6_EULER && p->integrator != R6_RK4 && p->integrator != R6_RK45) return fail(R6_E_BADARG, "bad integrator");
     if (p->n_substeps < 1 || p->n_substeps > 4096) return fail(R6_E_BADARG, "n_substeps out of range");
     if (p->shaping != R6_SHAPING_ACCELERATION && p->shaping != R6_SHAPING_VELOCITY)
         return fail(R6_E_BADARG, "bad shaping");
@@ -464,7 +474,7 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + r6::kBlock - 1) / 
 // Resident capacity (workgroups) of the current device for one step-kernel instance, cached.
 template <typename K>
 int resident_blocks(K kernel, int slot) {
-    static std::atomic<int> cache[16][8];
+    static std::atomic<int> cache[16][16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     int v = cache[dev][slot].load(std::memory_order_relaxed);
@@ -522,7 +532,12 @@ int r6_step(const R6Params* params, const R6Buffers* buf, uint64_t seed, uint64_
         return fail(R6_E_ALIGN, "r6_step: action and obs must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const R6Params& p = *params;
-    if (p.integrator == R6_RK4) {
+    if (p.integrator == R6_RK45) {
+        if (p.shaping == R6_SHAPING_ACCELERATION)
+            launch_step_od<R6_RK45, R6_SHAPING_ACCELERATION>(p, b, seed, step_index, env_offset, s);
+        else
+            launch_step_od<R6_RK45, R6_SHAPING_VELOCITY>(p, b, seed, step_index, env_offset, s);
+    } else if (p.integrator == R6_RK4) {
         if (p.shaping == R6_SHAPING_ACCELERATION)
             launch_step_od<R6_RK4, R6_SHAPING_ACCELERATION>(p, b, seed, step_index, env_offset, s);
         else
@@ -570,7 +585,9 @@ int r6_sim_step(const R6Params* params, float* state, const float* epconst, cons
     if (params->n_substeps < 1 || !(params->dt > 0.0f)) return fail(R6_E_BADARG, "bad dt / n_substeps");
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (params->integrator == R6_RK4)
+    if (params->integrator == R6_RK45)
+        hipLaunchKernelGGL((r6::sim_step_kernel<R6_RK45>), grid_for(n), dim3(r6::kBlock), 0, s, *params, state, epconst, u_phys, status, n, ld);
+    else if (params->integrator == R6_RK4)
         hipLaunchKernelGGL((r6::sim_step_kernel<R6_RK4>), grid_for(n), dim3(r6::kBlock), 0, s, *params, state, epconst, u_phys, status, n, ld);
     else if (params->integrator == R6_EULER)
         hipLaunchKernelGGL((r6::sim_step_kernel<R6_EULER>), grid_for(n), dim3(r6::kBlock), 0, s, *params, state, epconst, u_phys, status, n, ld);

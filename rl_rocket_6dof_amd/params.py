@@ -23,7 +23,7 @@ NUM_STATS = 8
 BLOCK = 256
 MAX_BLOCKS = 16384
 
-EULER, RK4 = 0, 1
+EULER, RK4, RK45 = 0, 1, 2
 SHAPING_ACCELERATION, SHAPING_VELOCITY = 0, 1
 FLAG_GROUND, FLAG_BOUNDS, FLAG_TRUNCATED = 1, 2, 4
 
@@ -63,7 +63,7 @@ class R6Buffers(C.Structure):
         ("state", C.c_void_p), ("epconst", C.c_void_p), ("action", C.c_void_p), ("obs", C.c_void_p),
         ("reward", C.c_void_p), ("done", C.c_void_p),
         ("flags", C.c_void_p), ("terms", C.c_void_p), ("final_obs", C.c_void_p), ("ep_step", C.c_void_p),
-        ("ep_return", C.c_void_p), ("fin_return", C.c_void_p), ("fin_length", C.c_void_p), ("stats", C.c_void_p),
+        ("ep_return", C.c_void_p), ("fin_return", C.c_void_p), ("fin_length", C.c_void_p), ("nfev", C.c_void_p), ("stats", C.c_void_p),
     ]
 
 
@@ -163,7 +163,7 @@ def make_params(env_config: dict, *, integrator: str = "rk4", n_substeps: Option
     dt = float(spec.timestep if timestep is None else timestep)
     p = R6Params()
     p.dt = dt
-    p.integrator = {"euler": EULER, "rk4": RK4}[integrator]
+    p.integrator = {"euler": EULER, "rk4": RK4, "rk45": RK45}[integrator]
     p.n_substeps = int(auto_substeps(dt) if n_substeps is None else n_substeps)
     p.shaping = SHAPING_ACCELERATION if spec.shaping_type == "acceleration" else SHAPING_VELOCITY
     p.max_gimbal = MAX_GIMBAL

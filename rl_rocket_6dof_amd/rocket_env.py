@@ -63,7 +63,7 @@ class Simulator6DOF:
         self.r_cp_B = [5, 0, 0]
         self._p = R6Params()
         self._p.dt = float(dt)
-        self._p.integrator = {"euler": 0, "rk4": 1}[integrator]
+        self._p.integrator = {"euler": 0, "rk4": 1, "rk45": 2}[integrator]
         self._p.n_substeps = int(auto_substeps(dt) if n_substeps is None else n_substeps)
         f32 = dict(dtype=torch.float32, device=self.device)
         self._ld = 64

@@ -25,6 +25,7 @@ def make(name):
     kw = dict(device=dev, record_flags=False, record_terms=False, track_episodes=False, seed=42, lib_path=libs.get(libname))
     if name == "rk4": return BatchedRocket6DOF(n, cfg, integrator="rk4", **kw)
     if name == "rk4_noreset": return BatchedRocket6DOF(n, cfg, integrator="rk4", auto_reset=False, **kw)
+    if name == "rk45": return BatchedRocket6DOF(n, cfg, integrator="rk45", **kw)
     if name == "euler": return BatchedRocket6DOF(n, cfg, integrator="euler", **kw)
     if name == "euler_dt004": return BatchedRocket6DOF(n, cfg, integrator="euler", timestep=0.04, **kw)
     if name == "rk4_wrapped":

@@ -424,3 +424,30 @@ def test_terminal_errors_montecarlo(torch_cuda, cfg):
     assert_close_scaled(te["attitude_error"].cpu().numpy(), 0.5 * np.rad2deg(np.arccos(post[:, 6])), 1.0, 1e-4, "attitude error")
     assert_close_scaled(te["angular_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 10:13], axis=1), 0.1, 1e-5, "omega error")
     assert_close_scaled(te["used mass"].cpu().numpy(), post[:, 13], 1.0, 1e-5, "terminal mass")
+
+
+@pytest.mark.parametrize("fixture", ["g3_env_rollouts.npz", "g4_ground_events.npz"])
+def test_rk45_adaptive_twin_vs_reference(torch_cuda, cfg, P, fixture):
+    """integrator="rk45": the in-kernel adaptive Dormand-Prince with scipy's step control and the
+    dense-output ground event (the algorithm of simulator.py:83-88 itself, in fp32).  Same 1e-5 bound,
+    same bit-exact masks; additionally the per-step RHS-evaluation count is compared with scipy's nfev."""
+    G = load_golden(fixture)
+    env, obs, rew, done, _ = _teacher_forced(torch_cuda, cfg, G, integrator="rk45", record_nfev=True)
+    _check_against_golden(env, obs, rew, done, G, P, fixture + " rk45")
+    nfev = env.nfev.cpu().numpy().astype(int)
+    same = float((nfev == G["nfev"]).mean())
+    print(f"[{fixture} rk45] nfev identical to scipy on {100 * same:.1f}% of the steps "
+          f"(mean {nfev.mean():.2f} vs {G['nfev'].mean():.2f})")
+    assert same > 0.97 and abs(nfev.mean() - G["nfev"].mean()) < 0.2
+
+
+def test_rk45_simulator_smoke_case_single_step(torch_cuda):
+    """test_6DOF_simulator.py:3-7 with the adaptive integrator: dt = 0.5 in ONE env step, like the reference."""
+    from rl_rocket_6dof_amd import Simulator6DOF
+
+    g1 = load_golden("g1_sim_step.npz")
+    sim = Simulator6DOF(list(g1["ic"]), integrator="rk45")
+    state, status = sim.step(list(g1["u"]))
+    assert status == 0
+    scale = np.array([100, 100, 100, 5, 5, 5, 1, 1, 1, 1, 1e-2, 1e-2, 1e-2, 5e4])
+    assert_close_scaled(state, g1["state"], scale, RTOL, "G1 Simulator6DOF.step rk45")
