@@ -689,6 +689,15 @@ __device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[
     return o;
 }
 
+// VerticalAttitudeReward term (wrappers.py:143-147): clip(2 * degrees(acos(q0)) * weight, -10, 10).
+// acos(q0) of the unit quaternion is taken as atan2(|q_v|, q0): near upright (q0 -> 1) acos is
+// ill-conditioned in fp32 (3e-5 relative at 2.6 deg), the vector part carries the angle exactly.
+// Out of line on purpose: it runs at touch-down only and atan2f's registers must not count against
+// the hot loop's 96-VGPR budget.
+__device__ __noinline__ float vertical_attitude_term(float q0, float qv, float weight) {
+    return fminf(fmaxf(2.0f * 57.29577951308232f * atan2f(qv, q0) * weight, -10.0f), 10.0f);
+}
+
 // Total step reward from the 7 terms: env:228-229 (bounds penalty) and the reference's optional reward
 // wrappers (my_environment/wrappers/wrappers.py).  `a2n` is the normalised throttle action, `q0` / `x` the
 // post-step attitude scalar and height.  May rewrite terms[] (annealed mode, vertical-attitude term).
@@ -707,11 +716,9 @@ __device__ __forceinline__ float finalize_reward(const R6Params& p, RewardOut& r
         r = rw.sum + (bnd ? p.bounds_penalty : 0.0f);
     }
     if (p.vatt_enable && x < p.vatt_threshold && rw.terms[6] > 0.0f) {
-        // VerticalAttitudeReward (wrappers.py:128-155): clip(2 * degrees(acos(q0)) * weight, -10, 10).
-        // acos(q0) of the unit quaternion is taken as atan2(|q_v|, q0): near upright (q0 -> 1) acos is
-        // ill-conditioned in fp32 (3e-5 relative at 2.6 deg), the vector part carries the angle exactly.
-        const float qv = sqrtf(fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
-        const float va = fminf(fmaxf(2.0f * 57.29577951308232f * atan2f(qv, q0) * p.vatt_weight, -10.0f), 10.0f);
+        // VerticalAttitudeReward (wrappers.py:128-155)
+        const float qv = fsqrt(fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
+        const float va = vertical_attitude_term(q0, qv, p.vatt_weight);
         rw.terms[7] = va;
         r += va;
     }

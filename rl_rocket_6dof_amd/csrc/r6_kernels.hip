@@ -209,7 +209,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
         //      us); the short Euler loop has too little work to hide that latency and keeps them resident. --
         bool bnd, done, truncated = false, landed;
         float rew;
-        float terms7[R6_NUM_TERMS];
         {
             const R6Params pr = [&]() __attribute__((always_inline)) {
                 if constexpr (INTEG == R6_RK4) return load_params();
@@ -226,9 +225,18 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
             RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
 #endif
             landed = rw.landed;
-            rew = finalize_reward(pr, rw, bnd, a2, y);
+            rew = finalize_reward(pr, rw, bnd, fmaf(2.0f * c.thrust, frcp(pr.max_thrust), -1.0f), y);   // a2 back from the thrust
+            if (live && opt_flags_terms) {   // per-term rewards (info["rewards_dict"]) leave here, so they die here
+                const R6Buffers bo = load_buffers();
+                if (bo.terms) {
+                    float* trow = bo.terms + e0;
 #pragma unroll
-            for (int q = 0; q < R6_NUM_TERMS; ++q) terms7[q] = rw.terms[q];
+                    for (int q = 0; q < R6_NUM_TERMS; ++q) {
+                        uniform_ptr(trow)[lane] = rw.terms[q];
+                        trow += bo.ld;
+                    }
+                }
+            }
             if (pr.clip_reward) rew = fminf(fmaxf(rew, pr.clip_lo), pr.clip_hi);
             ep_step += 1u;
             ep_ret += rew;
@@ -263,14 +271,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
                     uniform_ptr(bo.flags + e0)[lane] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
                                                                  (truncated ? R6_FLAG_TRUNCATED : 0));
                 if (bo.nfev) uniform_ptr(bo.nfev + e0)[lane] = (uint8_t)(nfev > 255 ? 255 : nfev);
-                if (bo.terms) {
-                    float* trow = bo.terms + e0;
-#pragma unroll
-                    for (int q = 0; q < R6_NUM_TERMS; ++q) {
-                        uniform_ptr(trow)[lane] = terms7[q];
-                        trow += bo.ld;
-                    }
-                }
             }
         }
 
