@@ -3,6 +3,7 @@
 set -e
 TAG=${1:-r1}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_trace.log 2>&1
