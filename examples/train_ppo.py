@@ -3,7 +3,7 @@
 make_env() stack (RemoveMassFromObs + ClipReward(-1,100) + TimeLimit(max_time/timestep) + Monitor), every
 environment on the GPU.
 
-    python examples/train_ppo.py --envs 65536 --timesteps 2e8
+    python examples/train_ppo.py --envs 65536 --timesteps 2e8 [--config config.yaml]
     torchrun --nproc-per-node 8 examples/train_ppo.py --envs 8388608      # env-sharded, RCCL grad all-reduce
 """
 import argparse

@@ -67,10 +67,33 @@ class R6Buffers(C.Structure):
     ]
 
 
+# Built-in defaults: the parameter set the reference trains with (the values of its config.yaml; any
+# YAML file with the same keys can be passed to load_config instead).
+_DEFAULT_ENV_CONFIG = {
+    "timestep": 0.1,
+    "seed": 42,
+    "reward_shaping_type": "acceleration",
+    #        x      y      z   vx    vy  vz   q0    q1 q2  q3   w1 w2 w3   mass
+    "IC": [2000, -1600, 0, -90, 180, 0, 0.866, 0, 0, -0.5, 0, 0, 0, 41.0e3],
+    "ICRange": [10, 200, 0, 30, 30, 0, 0.1, 0.1, 0.1, 0.1, 0.05, 0.05, 0.05, 1.0e3],
+    "trajectory_limits": {"attitude_limit": [85, 85, 360]},
+    "landing_params": {"waypoint": -1, "landing_radius": 30, "maximum_velocity": 10,
+                       "landing_attitude_limit": [10, 10, 360],   # [yaw, pitch, roll] deg, rotation order zyx
+                       "omega_lim": [0.2, 0.2, 0.2]},
+    "reward_coeff": {"alfa": -0.01, "beta": -1.0e-8, "gamma": -10, "delta": -5, "eta": 0.1, "kappa": 10, "xi": 0.004,
+                     "w_r_f": 0, "w_v_f": 0.75,     # 0 disables the corresponding terminal reward
+                     "max_r_f": 100, "max_v_f": 50},
+}
+_DEFAULT_SB3_CONFIG = {"env_id": "my_environment/Falcon6DOF-v0", "policy_type": "MlpPolicy",
+                       "total_timesteps": 20.0e6, "max_time": 150}
+
+
 def load_config(path: Optional[str] = None):
-    """``load_config()`` of the reference (main_6DOF.py:18-27): returns (sb3_config, env_config)."""
+    """``load_config()`` of the reference (main_6DOF.py:18-27): returns (sb3_config, env_config) from a
+    YAML file with the reference's layout, or the built-in defaults when no path is given."""
     if path is None:
-        path = os.path.join(os.path.dirname(__file__), "config.yaml")
+        import copy
+        return copy.deepcopy(_DEFAULT_SB3_CONFIG), copy.deepcopy(_DEFAULT_ENV_CONFIG)
     with open(path) as f:
         cfg = yaml.safe_load(f)
     return cfg["sb3_config"], cfg["env_config"]

@@ -130,3 +130,26 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "oracle_c" not in txt and "liboracle" not in txt, f
+
+
+def test_builtin_defaults_equal_reference_config_and_yaml_loader(tmp_path):
+    """The built-in defaults are the reference's config.yaml values (as recorded in the golden fixture), and a
+    YAML file with the reference's layout loads through load_config (main_6DOF.py:18-27)."""
+    import yaml
+
+    from rl_rocket_6dof_amd import default_env_config, load_config
+
+    ref = json.loads(str(load_golden("g3_env_rollouts.npz")["config"]))
+
+    def norm(d):
+        if isinstance(d, dict):
+            return {k: norm(v) for k, v in sorted(d.items())}
+        if isinstance(d, list):
+            return [float(x) for x in d]
+        return float(d) if isinstance(d, (int, float)) else d
+
+    assert norm(default_env_config()) == norm(ref)
+    f = tmp_path / "cfg.yaml"
+    f.write_text(yaml.safe_dump({"env_config": ref, "sb3_config": {"max_time": 150, "total_timesteps": 1e6}}))
+    sb3, env = load_config(str(f))
+    assert norm(env) == norm(ref) and sb3["max_time"] == 150
