@@ -157,7 +157,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar tile arithmetic
     float* tile = tiles[wave];
     const int64_t n = b.n;
-    const int64_t ld = b.ld;
     const int64_t n_tiles = (n + 63) >> 6;
     const int64_t nw = (int64_t)gridDim.x * kWaves;
     const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;

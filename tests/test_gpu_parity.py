@@ -451,3 +451,53 @@ def test_rk45_simulator_smoke_case_single_step(torch_cuda):
     assert status == 0
     scale = np.array([100, 100, 100, 5, 5, 5, 1, 1, 1, 1, 1e-2, 1e-2, 1e-2, 5e4])
     assert_close_scaled(state, g1["state"], scale, RTOL, "G1 Simulator6DOF.step rk45")
+
+
+def test_edge_cases_nan_unclipped_actions_substeps(torch_cuda, cfg, P):
+    """Edge cases the reference's semantics define: a non-finite position counts as a bounds violation
+    (gym Box.contains is False for NaN, rocket_env.py:591-593); actions are NOT clipped by the env
+    (rocket_env.py:509-521), so |a| > 1 must follow the same formulas (large gimbal angles take the
+    full-range sincos path); a 0.5 s env step is integrated as 5 RK4 sub-steps."""
+    torch = torch_cuda
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    G = load_golden("g3_env_rollouts.npz")
+    n = 256
+    pre = G["pre"][:n].astype(np.float32)
+    m0 = G["m0"][:n].astype(np.float32)
+    rng = np.random.RandomState(5)
+    act = rng.uniform(-3.5, 3.5, (n, 3)).astype(np.float32)       # far outside the Box
+    act[:, 2] = rng.uniform(-1.0, 1.6, n)
+    env = BatchedRocket6DOF(n, cfg, auto_reset=False, record_terms=True)
+    env.set_state(pre, m0=m0)
+    obs, rew, done, _ = env.step(torch.as_tensor(act, device=env.device))
+    post = env.get_state().cpu().numpy()
+    for i in range(0, n, 3):
+        o = onp.env_step(pre[i].astype(np.float64), float(m0[i]), act[i], P, "rk4")
+        assert bool(done[i]) == o["done"]
+        assert_close_scaled(post[i], o["post"], P.normalizer, RTOL, f"unclipped action env {i}")
+        assert_close_scaled(float(rew[i]), o["reward"], REWARD_SCALE, RTOL, f"unclipped action reward {i}")
+
+    bad = pre.copy()
+    bad[0, 0] = np.nan
+    bad[1, 1] = np.inf
+    env.set_state(bad, m0=m0)
+    obs, rew, done, _ = env.step(torch.zeros((n, 3), device=env.device))
+    fl = env.flags.cpu().numpy()
+    assert bool(done[0]) and bool(done[1]) and (fl[0] & 2) and (fl[1] & 2)
+
+    c5 = dict(cfg, timestep=0.5)
+    P5 = onp.OracleParams.from_config(c5)
+    env5 = BatchedRocket6DOF(n, c5, auto_reset=False)
+    assert env5.params.n_substeps == 5
+    env5.set_state(pre, m0=m0)
+    a5 = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    obs, rew, done, _ = env5.step(torch.as_tensor(a5, device=env5.device))
+    post = env5.get_state().cpu().numpy()
+    for i in range(0, n, 5):
+        o = onp.env_step(pre[i].astype(np.float64), float(m0[i]), a5[i], P5, "rk4", n_substeps=5)
+        oa = onp.env_step(pre[i].astype(np.float64), float(m0[i]), a5[i], P5, "adaptive")     # the reference's own integrator
+        assert bool(done[i]) == o["done"] == oa["done"]
+        assert_close_scaled(post[i], o["post"], P5.normalizer, RTOL, f"dt=0.5 env {i} vs fixed-step oracle")
+        assert_close_scaled(post[i], oa["post"], P5.normalizer, RTOL, f"dt=0.5 env {i} vs adaptive (reference) oracle")
