@@ -132,10 +132,22 @@ int oc_sim_step(double *y, const float u[3], double m0, double dt, int rk4, int 
         if (cross) {
             status = 1;
             if (rk4) {
-                double d0 = h * y[3], d1 = h * y1[3], D = (y1[0] - y[0]) - d0, E = d1 - d0;
-                double c[4] = {y[0], d0, 3 * D - E, -2 * D + E};
-                double th = poly_root01(c, 4, y[0], y1[0]);
-                map_step(y, u, m0, th * h, 1, y1);
+                /* Hermite dense output of the step with exact end slopes -- oracle_np.event_step_rk4 */
+                double f0[NS], f1[NS], d0[NS], c2[NS], c3[NS], ye[NS];
+                oc_rhs(y, u, m0, f0);
+                oc_rhs(y1, u, m0, f1);
+                for (int i = 0; i < NS; ++i) {
+                    d0[i] = h * f0[i];
+                    double D = (y1[i] - y[i]) - d0[i], E = h * f1[i] - d0[i];
+                    c2[i] = 3 * D - E;
+                    c3[i] = E - 2 * D;
+                }
+                double c[5] = {y[0], h * y[3], h * (d0[3] / 2), h * (c2[3] / 3), h * (c3[3] / 4)};
+                double th = poly_root01(c, 5, y[0], y1[0]);
+                for (int i = 0; i < NS; ++i) ye[i] = y[i] + th * (d0[i] + th * (c2[i] + th * c3[i]));
+                for (int i = 0; i < 3; ++i)
+                    ye[i] = y[i] + (h * th) * (y[3 + i] + th * (d0[3 + i] / 2 + th * (c2[3 + i] / 3 + th * (c3[3 + i] / 4))));
+                memcpy(y1, ye, sizeof(ye));
                 if (y1[3] != 0.0) {
                     double delta = -y1[0] / y1[3];
                     if (fabs(delta) <= h) for (int i = 0; i < 3; ++i) y1[i] += y1[3 + i] * delta;

@@ -145,13 +145,12 @@ __device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
     return R;
 }
 
-// sim:106-143 -- derivative of the 13 dynamic components; `im` = 1 / mass at this time.
-__device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Control& c, const Inertia& J,
-                                      float (&dy)[kDyn]) {
+// sim:106-143 -- the force / torque half of the RHS: dv[3] = d(v)/dt, dw[2] = d(omega_y, omega_z)/dt
+// (d(omega_x)/dt == 0, see below); `im` = 1 / mass at this time.
+__device__ __forceinline__ void rhs_dyn(const float (&y)[kDyn], float im, const Control& c, const Inertia& J,
+                                        float (&dv)[3], float (&dw)[2]) {
     const float vx = y[3], vy = y[4], vz = y[5];
-    const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
-    const float wx = y[10], wy = y[11], wz = y[12];
-    const Rot R = rotmat(q0, q1, q2, q3);
+    const Rot R = rotmat(y[6], y[7], y[8], y[9]);
 
     // aero (sim:216-219): A_B = -k rho |v| R^T v ; rotated back: A_I = -k rho |v| v
     const float speed = fsqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
@@ -163,38 +162,60 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Co
     const float fx = fmaf(R.r00, c.tbx, fmaf(R.r01, c.tby, fmaf(R.r02, c.tbz, ca * vx)));
     const float fy = fmaf(R.r10, c.tbx, fmaf(R.r11, c.tby, fmaf(R.r12, c.tbz, ca * vy)));
     const float fz = fmaf(R.r20, c.tbx, fmaf(R.r21, c.tby, fmaf(R.r22, c.tbz, ca * vz)));
-    dy[0] = vx;
-    dy[1] = vy;
-    dy[2] = vz;
-    dy[3] = fmaf(fx, im, -(float)kG0);
-    dy[4] = fy * im;
-    dy[5] = fz * im;
-
-    // quaternion kinematics (sim:133-136, :221-229): qdot = 1/2 Omega(w) q
-    dy[6] = -0.5f * fmaf(wx, q1, fmaf(wy, q2, wz * q3));
-    dy[7] = 0.5f * fmaf(wx, q0, fmaf(wz, q2, -wy * q3));
-    dy[8] = 0.5f * fmaf(wy, q0, fmaf(-wz, q1, wx * q3));
-    dy[9] = 0.5f * fmaf(wz, q0, fmaf(wy, q1, -wx * q2));
+    dv[0] = fmaf(fx, im, -(float)kG0);
+    dv[1] = fy * im;
+    dv[2] = fz * im;
 
     // rotational (sim:137, :232-244): tau = r_T x T_B + r_cp x A_B with r = [rx,0,0]
     //   -> tau = (0, -rT*tbz - rcp*abz, rT*tby + rcp*aby);  J = diag(Jx,Jt,Jt):
     //   w x Jw = (0, (Jx-Jt) wx wz, (Jt-Jx) wx wy)  => wx is constant
     const float tauy = fmaf(-(float)kArmThrust, c.tbz, -(float)kArmCp * abz);
     const float tauz = fmaf((float)kArmThrust, c.tby, (float)kArmCp * aby);
-    const float g = J.jdiff * wx;
-    dy[10] = 0.0f;
-    dy[11] = (tauy - g * wz) * J.inv_jt;
-    dy[12] = (tauz + g * wy) * J.inv_jt;
+    const float g = J.jdiff * y[10];
+    dw[0] = (tauy - g * y[12]) * J.inv_jt;
+    dw[1] = (tauz + g * y[11]) * J.inv_jt;
 }
 
+// quaternion kinematics (sim:133-136, :221-229): qdot = 1/2 Omega(w) q
+__device__ __forceinline__ void rhs_quat(const float (&y)[kDyn], float (&dq)[4]) {
+    const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
+    const float wx = y[10], wy = y[11], wz = y[12];
+    dq[0] = -0.5f * fmaf(wx, q1, fmaf(wy, q2, wz * q3));
+    dq[1] = 0.5f * fmaf(wx, q0, fmaf(wz, q2, -wy * q3));
+    dq[2] = 0.5f * fmaf(wy, q0, fmaf(-wz, q1, wx * q3));
+    dq[3] = 0.5f * fmaf(wz, q0, fmaf(wy, q1, -wx * q2));
+}
+
+// sim:106-143 -- derivative of the 13 dynamic components; `im` = 1 / mass at this time.
+__device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Control& c, const Inertia& J,
+                                      float (&dy)[kDyn]) {
+    float dv[3], dw[2], dq[4];
+    rhs_dyn(y, im, c, J, dv, dw);
+    rhs_quat(y, dq);
+    dy[0] = y[3];
+    dy[1] = y[4];
+    dy[2] = y[5];
+    dy[3] = dv[0];
+    dy[4] = dv[1];
+    dy[5] = dv[2];
+    dy[6] = dq[0];
+    dy[7] = dq[1];
+    dy[8] = dq[2];
+    dy[9] = dq[3];
+    dy[10] = 0.0f;
+    dy[11] = dw[0];
+    dy[12] = dw[1];
+}
+
+// One application of the Euler / RK4 map.
 template <int INTEG>
 __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, const Control& c, const Inertia& J,
                                          float h, float (&y1)[kDyn]) {
+    float kend[kDyn];
     if constexpr (INTEG == R6_EULER) {
-        float k[kDyn];
-        rhs13(y0, frcp(mass), c, J, k);
+        rhs13(y0, frcp(mass), c, J, kend);
 #pragma unroll
-        for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h, k[i], y0[i]);
+        for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h, kend[i], y0[i]);
     } else {
         // Classical RK4 as a rolled loop over the four stages (one copy of the RHS in the instruction
         // stream, register footprint of a single stage):  y1 accumulates y0 + h/6 (k1 + 2k2 + 2k3 + k4),
@@ -212,13 +233,12 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
             const float tm = (s == 0) ? 0.0f : ((s == 3) ? h : hh);      // stage time offset
             const float w = (s == 0 || s == 3) ? h6 : 2.0f * h6;         // quadrature weight * h
             const float an = (s == 2) ? h : hh;                          // next stage's step
-            float k[kDyn];
-            rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, k);
+            rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, kend);
 #pragma unroll
             for (int i = 0; i < kDyn; ++i) {
                 if (i == 10) continue;   // d(omega_x)/dt == 0 exactly (rhs13): omega_x stays y0[10]
-                y1[i] = fmaf(w, k[i], y1[i]);
-                yt[i] = fmaf(an, k[i], y0[i]);
+                y1[i] = fmaf(w, kend[i], y1[i]);
+                yt[i] = fmaf(an, kend[i], y0[i]);
             }
         }
     }
@@ -258,16 +278,20 @@ __device__ __forceinline__ float poly_root01(const float (&c)[N], float x0, floa
 
 // One env step of the simulator (sim:69-104) with fixed sub-steps.
 //
-// Ground event (oracle_np.event_step_rk4): theta = root of the cubic Hermite interpolant of x over
-// the sub-step, then the SAME step map is applied again with the step shortened to theta*h, and a
-// final Newton correction in time (positions only) puts the state on x = 0.
+// Ground event (oracle_np.event_step_rk4) -- the reference returns its integrator's dense output at the
+// event time (sim:77-90 / scipy ivp.py); the fixed-step twin does the same with a Hermite dense output of
+// the RK4 step through its end points with the exact end slopes f0 = f(y0), f1 = f(y1) (two RHS
+// evaluations; a second, shortened RK4 step would cost four and is no closer to the reference):
+//   v, q, omega:  Y(th) = y0 + th (d0 + th (c2 + th c3)),  d0 = h f0, d1 = h f1,
+//                 D = (y1 - y0) - d0, E = d1 - d0, c2 = 3D - E, c3 = E - 2D      (cancellation-free form)
+//   r:            R(th) = r0 + h th (v0 + th (d0/2 + th (c2/3 + th c3/4)))   (integral of v's interpolant)
+//   1. theta = root in [0,1] of the x component of R (a quartic);  2. state = (R, Y)(theta);
+//   3. one Newton correction in time on the position only: delta = -x/vx, r += v delta.
+// Euler: the map is linear in h, so theta = x0/(x0-x1) and the state is y0 + theta (y1 - y0).
 //
 // EVENTS = true : full semantics, returns status (1 = ground event handled).
-// EVENTS = false: hot-loop flavour -- the step map is applied once per sub-step; if a sub-step
-//                 crosses the ground the function stops and returns 1 WITHOUT producing the event
-//                 state (the caller re-runs that env through the EVENTS = true flavour in its dense
-//                 deferred pass).  This keeps the rare second trip through the integrator out of
-//                 the wave-divergent hot loop.
+// EVENTS = false: the crossing sub-step stops the integration with status 1 WITHOUT producing the event
+//                 state (timing experiments only).
 template <int INTEG, bool EVENTS>
 __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J,
                                          float dt, int nsub) {
@@ -278,37 +302,60 @@ __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Co
         if (status != 0) continue;
         float y1[kDyn];
         float hs = h;
-#pragma unroll 1
-        for (int pass = 0; pass < (EVENTS ? 2 : 1); ++pass) {
-            step_map<INTEG>(y, mass, c, J, hs, y1);
-            if (pass == 1) {
+        step_map<INTEG>(y, mass, c, J, h, y1);
+        if (crossing(y[0], y1[0])) {
+            status = 1;
+            if constexpr (EVENTS) {
                 if constexpr (INTEG == R6_RK4) {
+                    // end slopes of v and (omega_y, omega_z); the quaternion's are formed where they are used
+                    float a0[3], a1[3], w0[2], w1[2];
+                    rhs_dyn(y1, frcp(fmaf(-c.mdot, h, mass)), c, J, a1, w1);
+                    rhs_dyn(y, frcp(mass), c, J, a0, w0);
+                    float d0v[3], c2v[3], c3v[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {      // velocity coefficients first: the x quartic needs vx's
+                        d0v[i] = h * a0[i];
+                        const float D = (y1[3 + i] - y[3 + i]) - d0v[i];
+                        const float E = fmaf(h, a1[i], -d0v[i]);
+                        c2v[i] = fmaf(3.0f, D, -E);
+                        c3v[i] = fmaf(-2.0f, D, E);
+                    }
+                    const float cx[5] = {y[0], h * y[3], h * (0.5f * d0v[0]), h * (c2v[0] * (1.0f / 3.0f)),
+                                         h * (0.25f * c3v[0])};
+                    const float th = poly_root01(cx, y[0], y1[0]);
+                    const float hth = h * th;
+                    float dq0[4], dq1[4];
+                    rhs_quat(y, dq0);
+                    rhs_quat(y1, dq1);
+                    auto hermite = [&](float ya, float yb, float fa, float fb) {
+                        const float e0 = h * fa;
+                        const float D = (yb - ya) - e0;
+                        const float E = fmaf(h, fb, -e0);
+                        return fmaf(th, fmaf(th, fmaf(th, fmaf(-2.0f, D, E), fmaf(3.0f, D, -E)), e0), ya);
+                    };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y1[6 + i] = hermite(y[6 + i], y1[6 + i], dq0[i], dq1[i]);
+                    y1[11] = hermite(y[11], y1[11], w0[0], w1[0]);
+                    y1[12] = hermite(y[12], y1[12], w0[1], w1[1]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float q4 = fmaf(th, 0.25f * c3v[i], c2v[i] * (1.0f / 3.0f));
+                        y1[i] = fmaf(hth, fmaf(th, fmaf(th, q4, 0.5f * d0v[i]), y[3 + i]), y[i]);
+                        y1[3 + i] = fmaf(th, fmaf(th, fmaf(th, c3v[i], c2v[i]), d0v[i]), y[3 + i]);
+                    }
                     const float delta = -y1[0] / y1[3];
                     if (y1[3] != 0.0f && fabsf(delta) <= h) {
                         y1[0] = fmaf(y1[3], delta, y1[0]);
                         y1[1] = fmaf(y1[4], delta, y1[1]);
                         y1[2] = fmaf(y1[5], delta, y1[2]);
                     }
-                }
-                break;
-            }
-            if (!crossing(y[0], y1[0])) break;
-            status = 1;
-            if constexpr (!EVENTS) break;
-            float th;
-            if constexpr (INTEG == R6_RK4) {
-                const float d0 = h * y[3], d1 = h * y1[3];
-                const float D = (y1[0] - y[0]) - d0;
-                const float E = d1 - d0;
-                const float cc[4] = {y[0], d0, 3.0f * D - E, -2.0f * D + E};
-                th = poly_root01(cc, y[0], y1[0]);
-                hs = th * h;      // second pass: re-apply the map with the shortened step
-            } else {              // the Euler map is linear in h: interpolate, no second pass
-                th = (y[0] == 0.0f) ? 0.0f : y[0] / (y[0] - y1[0]);
+                    hs = hth;
+                } else {
+                    const float th = (y[0] == 0.0f) ? 0.0f : y[0] / (y[0] - y1[0]);
 #pragma unroll
-                for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(th, y1[i] - y[i], y[i]);
-                hs = th * h;
-                break;
+                    for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(th, y1[i] - y[i], y[i]);
+                    hs = th * h;
+                }
             }
         }
 #pragma unroll

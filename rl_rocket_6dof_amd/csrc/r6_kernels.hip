@@ -39,7 +39,10 @@ __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) 
 //     SGPRs across the loop.
 // -------------------------------------------------------------------------------------------------
 constexpr int kWaves = kBlock / 64;
-constexpr int kResetQueueCap = 2048;
+#ifndef R6_RESET_QUEUE
+#define R6_RESET_QUEUE 2048
+#endif
+constexpr int kResetQueueCap = R6_RESET_QUEUE;
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS instructions of one wave execute in order; this only stops the compiler from moving
@@ -136,10 +139,16 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
     }
 }
 
+#ifndef R6_RK4_WAVES
+#define R6_RK4_WAVES 5
+#endif
+#ifndef R6_EULER_WAVES
+#define R6_EULER_WAVES 5
+#endif
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
 template <int INTEG, int SHAPING, int OD>
-__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
+__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
@@ -163,6 +172,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
     const bool opt_flags_terms = b.flags != nullptr || b.terms != nullptr || b.nfev != nullptr;
 
+#ifdef R6_PHASE_TIMING   // dev build: 100 MHz wall-clock stamps per workgroup instead of the episode statistics
+    const uint64_t pt0 = wall_clock64();
+#endif
     if (tid == 0) rq_count = 0;
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
     if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
     // One 64-env tile.  FULL = all 64 lanes are live (every tile but possibly the last one).
     auto process_tile = [&](const int64_t e0, const TileIn& in, auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
+        bool overflow = false;       // this lane's finished episode did not fit into the reset queue
         const int64_t rem = n - e0;  // envs from the tile's start to the end of the shard (> 0)
         const bool live = FULL ? true : (lane < rem);
         float y[kDyn];
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
         const Control c = make_control_normalised(p, a0, a1, a2);
         const Inertia J = make_inertia(m0);
 #ifdef R6_ABLATE_INTEG   // timing-only build: dynamics skipped, inputs kept live
-        int status = 0;
+        int status = 0, nfev = 0;
         asm volatile("" :: "v"(c.tbx), "v"(c.tby), "v"(c.tbz), "v"(J.inv_jt), "v"(J.jdiff));
         y[3] += p.dt * c.mdot;
 #else
@@ -200,6 +213,12 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
             nfev = (INTEG == R6_RK4 ? 4 : 1) * p.n_substeps;
         }
 #endif
+
+        // `ln` = the lane id again, opaque to the optimiser: everything addressed after the integration is
+        // re-derived from it here instead of being hoisted out of the tile loop and kept in VGPRs across
+        // the RK4 stages (where the register budget of 5 waves/SIMD is decided).
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 
         // ---- termination (env:213, :591-593), reward (env:215, :228-229, :317-402),
         //      fused ClipReward / TimeLimit / Monitor (main_6DOF.py:33-51).  In the RK4 instances the
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
                     float* trow = bo.terms + e0;
 #pragma unroll
                     for (int q = 0; q < R6_NUM_TERMS; ++q) {
-                        uniform_ptr(trow)[lane] = rw.terms[q];
+                        uniform_ptr(trow)[ln] = rw.terms[q];
                         trow += bo.ld;
                     }
                 }
@@ -251,34 +270,34 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
                 if constexpr (INTEG == R6_RK4) return load_buffers();
                 else return b;
             }();
-            uniform_ptr(bs.reward + e0)[lane] = rew;
-            uniform_ptr(bs.done + e0)[lane] = done ? 1 : 0;
+            uniform_ptr(bs.reward + e0)[ln] = rew;
+            uniform_ptr(bs.done + e0)[ln] = done ? 1 : 0;
             float* row = bs.state + e0;
 #pragma unroll
             for (int j = 0; j < kDyn; ++j) {
-                uniform_ptr(row)[lane] = y[j];
+                uniform_ptr(row)[ln] = y[j];
                 row += bs.ld;
             }
-            uniform_ptr(row)[lane] = mass;
+            uniform_ptr(row)[ln] = mass;
             if (has_ep) {
-                uniform_ptr(bs.ep_step + e0)[lane] = ep_step;
-                uniform_ptr(bs.ep_return + e0)[lane] = ep_ret;
+                uniform_ptr(bs.ep_step + e0)[ln] = ep_step;
+                uniform_ptr(bs.ep_return + e0)[ln] = ep_ret;
             }
             if (opt_flags_terms) {   // optional outputs: their pointers are fetched only when present
                 const R6Buffers bo = load_buffers();
                 if (bo.flags)
-                    uniform_ptr(bo.flags + e0)[lane] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
+                    uniform_ptr(bo.flags + e0)[ln] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) |
                                                                  (truncated ? R6_FLAG_TRUNCATED : 0));
-                if (bo.nfev) uniform_ptr(bo.nfev + e0)[lane] = (uint8_t)(nfev > 255 ? 255 : nfev);
+                if (bo.nfev) uniform_ptr(bo.nfev + e0)[ln] = (uint8_t)(nfev > 255 ? 255 : nfev);
             }
         }
 
         // ---- observation (env:503-504): registers -> LDS row-major tile ---------------------------------
 #pragma unroll
         for (int j = 0; j < kDyn; ++j) {
-            if (j < OD) tile[lane * OD + j] = y[j] * lds_inv_norm[j];
+            if (j < OD) tile[ln * OD + j] = y[j] * lds_inv_norm[j];
         }
-        if (OD == 14) tile[lane * OD + (OD - 1)] = mass * lds_inv_norm[13];
+        if (OD == 14) tile[ln * OD + (OD - 1)] = mass * lds_inv_norm[13];
 
         // ---- finished episodes: terminal outputs now; the re-sampling (env:180-199) is deferred to
         //      the dense drain after the loop, which overwrites state / obs / counters of these envs ---
@@ -295,19 +314,20 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
                 if (landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
             }
             if (p.auto_reset) {
-                const int64_t i = e0 + lane;
+                const int64_t i = e0 + ln;
                 if (bb.final_obs) {
 #pragma unroll
-                    for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = tile[lane * OD + j];
+                    for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = tile[ln * OD + j];
                 }
                 if (bb.fin_return) bb.fin_return[i] = ep_ret;
                 if (bb.fin_length) bb.fin_length[i] = ep_step;
                 const int slot = atomicAdd(&rq_count, 1);
-                if (slot < kResetQueueCap) rq[slot] = (int)i;  // overflow: found again by the drain's scan
+                if (slot < kResetQueueCap) rq[slot] = (int)i;
+                else overflow = true;   // queue full (mass termination): re-sampled by the tile loop itself
             }
         }
 
-        // ---- LDS tile -> contiguous 16 B-per-lane stores of the (64, OD) observation block ---------------
+        // ---- LDS tile -> contiguous 16 B-per-ln stores of the (64, OD) observation block ---------------
         wave_lds_sync();
         {
             const gptr<float> dst = uniform_ptr(((INTEG == R6_RK4) ? load_buffers().obs : b.obs) + e0 * OD);
@@ -315,59 +335,102 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 5)) void step_kerne
                 constexpr int n4 = 64 * OD / 4;
 #pragma unroll
                 for (int k = 0; k < (n4 + 63) / 64; ++k) {
-                    const int q = lane + 64 * k;
+                    const int q = ln + 64 * k;
                     if (q < n4) *(gptr<f4>)(dst + 4 * q) = ld4(&tile[4 * q]);
                 }
             } else {
-                for (int k = lane; k < (int)rem * OD; k += 64) dst[k] = tile[k];
+                for (int k = ln; k < (int)rem * OD; k += 64) dst[k] = tile[k];
             }
         }
         wave_lds_sync();  // before the next tile overwrites the LDS tile
+        return overflow;
     };
 
     // Tile loop.  (Measured alternatives that did not pay at N = 2^20, where the loop is VALU-bound:
     // register prefetch of the next tile -- +30 VGPRs, one wave per SIMD less, no gain; deferring
     // ground-event envs to the dense pass -- its serial tail per workgroup costs more than the
     // divergence it removes.)
+    //
+    // Wave priorities.  The SIMD arbiter serves its oldest wave first, so at equal priority the waves of the
+    // workgroups dispatched first run ahead and finish at ~60 % of the launch, and the last quarter of the
+    // launch runs on the few waves that were starved until then, with nothing left to hide their latencies
+    // behind (wall-clock stamps per wave: scripts/phase_timing.py).  Each wave therefore lowers its own
+    // priority as it completes tiles: laggards go first, the waves of a SIMD advance together and the tail
+    // shrinks (A/B at N = 2^20: 42.3 -> 40.2 us).  Handing the tiles out dynamically instead (one fetch-add
+    // counter per group of 20 workgroups; a single counter serialises at 11 ns per fetch-add) was measured
+    // too and changes nothing: what is left of the spread in wave end times (~one tile time of 8-10 us) is
+    // the ramp of the first loads -- 5120 waves ask for 30 MB at t = 0 and are served over ~6 us.
     const int64_t n_full = n >> 6;  // tiles [0, n_full) are full; tile n_full (if any) is partial
+    int tile_no = 0;
 #pragma unroll 1
     for (int64_t t = t_first; t < n_tiles; t += nw) {
+        if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
+        else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
+        else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        ++tile_no;
         TileIn cur;
+        bool overflow;
         if (t < n_full) {
             load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
-            process_tile(t * 64, cur, std::true_type{});
+            overflow = process_tile(t * 64, cur, std::true_type{});
         } else {
             load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
-            process_tile(t * 64, cur, std::false_type{});
+            overflow = process_tile(t * 64, cur, std::false_type{});
+        }
+        if (__builtin_expect(__any(overflow), 0)) {
+            // Reset queue full (mass termination, e.g. the first landing wave of envs started in lockstep):
+            // these lanes re-sample their env right here, once the tile's terminal outputs have left the wave.
+            __builtin_amdgcn_s_waitcnt(0);
+            if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 
+#ifdef R6_PHASE_TIMING
+    const uint64_t pt1 = wall_clock64();
+#endif
     // __syncthreads() drains every wave's outstanding stores (s_waitcnt vmcnt(0)) before the barrier,
     // so the drain below overwrites the terminal state / obs of the finished envs in order.
     __syncthreads();
+#ifdef R6_PHASE_TIMING
+    const uint64_t pt2 = wall_clock64();
+#endif
 
     const int n_queued = rq_count;
     if (n_queued > 0) {
         const R6Buffers bb = load_buffers();
+#ifndef R6_PHASE_TIMING
         if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
+#endif
 
         // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
         const R6Params pp = load_params();
-        if (n_queued <= kResetQueueCap) {
-            for (int k = tid; k < n_queued; k += kBlock)
-                reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
-        } else {
-            // queue overflow (mass termination): rescan the done flags of this workgroup's tiles
-            for (int64_t tt = t_first; tt < n_tiles; tt += nw) {
-                const int64_t ii = tt * 64 + lane;
-                if (ii < bb.n && bb.done[ii]) reset_env_global<OD>(pp, bb, ii, seed, step_index, env_offset);
-            }
-        }
+        const int n_rec = n_queued < kResetQueueCap ? n_queued : kResetQueueCap;   // the rest was handled in the loop
+        for (int k = tid; k < n_rec; k += kBlock)
+            reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
     } else if (!p.auto_reset) {
         const R6Buffers bb = load_buffers();
+#ifndef R6_PHASE_TIMING
         if (bb.stats && tid < R6_NUM_STATS && blk_stats[0] > 0.0f)
             bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
+#endif
     }
+#ifdef R6_PHASE_TIMING
+    if (b.stats && (tid & 63) == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t pt3 = wall_clock64();
+        float* o = b.stats + (int64_t)blockIdx.x * R6_NUM_STATS;
+        if (tid == 0) {
+            o[0] = __uint_as_float((uint32_t)pt0);
+            o[2] = __uint_as_float((uint32_t)pt2);
+            o[3] = __uint_as_float((uint32_t)pt3);
+            o[7] = __uint_as_float((uint32_t)n_queued);
+        }
+        // per-wave end of the tile loop: slots 1 (wave 0), 4, 5, 6 (waves 1..3)
+        o[wave == 0 ? 1 : 3 + wave] = __uint_as_float((uint32_t)pt1);
+    }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -141,3 +141,41 @@ def test_physical_invariants_over_a_rollout(torch_cuda, cfg):
         assert float((s1[:, 10] - s0[:, 10])[alive].abs().max()) == 0.0
         inv = torch.as_tensor(1.0 / env.state_normalizer, dtype=torch.float32, device=env.device)
         assert float((obs - s1 * inv).abs().max()) < 1e-6
+
+
+def test_mass_termination_overflows_the_reset_queue(torch_cuda, cfg):
+    """Every env of a 4 M batch ends its episode in the same step (all placed outside the position bounds):
+    ~3300 finished episodes per workgroup, more than its LDS reset queue holds, so the overflow path of the
+    tile loop re-samples the excess.  Every env must come out re-sampled exactly as the oracle's Philox
+    stream prescribes for (seed, step_index, global env id), with the terminal observation preserved."""
+    torch = torch_cuda
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n = 1 << 22
+    env = BatchedRocket6DOF(n, cfg, seed=99, env_offset=12345, record_flags=True, track_episodes=True)
+    env.reset()
+    st = env.get_state()
+    st[:, 1] = 1.0e6                       # far outside the y bounds -> done on the next step
+    env.set_state(st)
+    before = env.get_state()
+    obs, rew, done, _ = env.step(torch.zeros((n, 3), device=env.device))
+    torch.cuda.synchronize()
+    assert bool(done.all())
+    assert bool(((env.flags & 2) != 0).all())
+    assert int(env.episode_stats(clear=False)["episodes"]) == n
+    after = env.get_state()
+    assert bool((after[:, 1].abs() < 1.0e5).all()), "an env was left in its terminal state"
+    assert bool((env.ep_step == 0).all())
+    assert bool((env.final_obs[:, 1] > 100.0).all()), "terminal observation must be the pre-reset one"
+    assert bool((env.fin_length == 1).all())
+    P = onp.OracleParams.from_config(cfg)
+    a = after.cpu().numpy()
+    plain = [0, 1, 2, 3, 4, 5, 10, 11, 12, 13]
+    rng = np.random.default_rng(0)
+    for i in np.concatenate([rng.integers(0, n, 400), [0, 63, 64, n - 1]]):
+        want = onp.reset_sample(99, 12345 + int(i), env._step_count, P)
+        np.testing.assert_array_equal(a[i, plain], want[plain])
+        np.testing.assert_allclose(a[i, 6:10], want[6:10], rtol=0, atol=1.2e-7)
+    np.testing.assert_allclose(obs.cpu().numpy()[::4097], a[::4097] / P.normalizer, rtol=3e-7, atol=1e-9)
+    assert not torch.equal(before, after)
