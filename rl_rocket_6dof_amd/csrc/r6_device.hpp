@@ -207,6 +207,10 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Co
     dy[12] = dw[1];
 }
 
+#ifndef R6_RK4_ROLLED
+#define R6_RK4_ROLLED 0
+#endif
+
 // One application of the Euler / RK4 map.
 template <int INTEG>
 __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, const Control& c, const Inertia& J,
@@ -228,7 +232,11 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
             yt[i] = y0[i];
             y1[i] = y0[i];
         }
+#if R6_RK4_ROLLED
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
         for (int s = 0; s < 4; ++s) {
             const float tm = (s == 0) ? 0.0f : ((s == 3) ? h : hh);      // stage time offset
             const float w = (s == 0 || s == 3) ? h6 : 2.0f * h6;         // quadrature weight * h
