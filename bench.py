@@ -83,15 +83,15 @@ def cpu_baseline_c(seconds: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=1 << 20)
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "euler"])
     ap.add_argument("--dt", type=float, default=None, help="env timestep (default: config.yaml 0.1)")
     ap.add_argument("--variant", default="raw", choices=["raw", "wrapped"],
                     help="raw = Rocket6DOF.step (189 B); wrapped = fused make_env() stack (201 B)")
     ap.add_argument("--pool", type=int, default=8, help="number of pre-generated action buffers")
-    ap.add_argument("--burnin", type=int, default=300,
+    ap.add_argument("--burnin", type=int, default=2000,
                     help="untimed auto-reset steps run once after reset(), before warmup: all envs start in lockstep, "
                          "so without it the timed region would sit on the first mass-termination wave instead of the "
                          "steady mix of flight phases")

@@ -124,7 +124,7 @@ typedef struct R6Buffers {
     uint8_t *done;        /* [n]       out: exactly 0 or 1 */
     /* ---- optional outputs / state: NULL to skip ---- */
     uint8_t *flags;       /* [n]       out: R6_FLAG_* bits */
-    float *terms;         /* [7][ld]   out: per-term rewards (info["rewards_dict"]) */
+    float *terms;         /* [8][ld]   out: per-term rewards (info["rewards_dict"]) */
     float *final_obs;     /* (n,obs_dim) out: rows of done envs only ("terminal_observation") */
     uint32_t *ep_step;    /* [n]       in/out: steps elapsed in the episode (TimeLimit/Monitor) */
     float *ep_return;     /* [n]       in/out: running episode return (Monitor) */

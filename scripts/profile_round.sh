@@ -18,7 +18,7 @@ rows = list(csv.DictReader(open(f)))
 out["kernel_stats_top"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows[:6]]
 tr = glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True)[0]
 st = [r for r in csv.DictReader(open(tr)) if "step_kernel" in r["Kernel_Name"]]
-d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in st][-200:]
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in st][-2000:]   # = the timed region (bench.py default --steps)
 out["step_kernel_timed_region"] = {"launches": len(d), "avg_us": sum(d) / len(d), "min_us": min(d), "max_us": max(d),
                                    "vgpr": st[-1]["VGPR_Count"], "sgpr": st[-1]["SGPR_Count"], "lds": st[-1]["LDS_Block_Size"],
                                    "grid": st[-1]["Grid_Size_X"], "workgroup": st[-1]["Workgroup_Size_X"]}
