@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define R6_ABI_VERSION 2
+#define R6_ABI_VERSION 3
 #define R6_STATE_DIM 14
 #define R6_ACTION_DIM 3
 #define R6_NUM_TERMS 8 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
@@ -166,6 +166,38 @@ int r6_sim_step(const R6Params *params, float *state, const float *epconst, cons
 /* Simulator6DOF.RHS (simulator.py:106-143): dy[14][ld] <- f(y[14][ld], u_phys (n,3)). */
 int r6_rhs(const R6Params *params, const float *y, const float *epconst, const float *u_phys,
            float *dy, int64_t n, int64_t ld, void *stream);
+
+/* ---- rollout-side policy forward (the caller of r6_step in a PPO rollout) -------------------------------
+ * SB3 1.6 `ActorCriticPolicy` as the reference builds it (`PPO("MlpPolicy", env, policy_kwargs=
+ * {'net_arch': [128, 64]})`, main_6DOF.py:107-139; SB3 default net_arch (64, 64)): separate tanh MLPs for
+ * policy and value, state-independent log_std, diagonal Gaussian.  Weights are device pointers to fp32
+ * arrays in torch.nn.Linear layout ([out][in] row-major), not copied: the launch reads them. */
+typedef struct R6PolicyNet {
+    int32_t obs_dim;            /* 13 | 14 (= R6Params.obs_dim) */
+    int32_t hidden1, hidden2;   /* (64, 64) or (128, 64) */
+    int32_t reserved0;
+    const float *pi_w1, *pi_b1; /* [hidden1][obs_dim], [hidden1] */
+    const float *pi_w2, *pi_b2; /* [hidden2][hidden1], [hidden2] */
+    const float *pi_w3, *pi_b3; /* [3][hidden2], [3]   (action mean) */
+    const float *vf_w1, *vf_b1;
+    const float *vf_w2, *vf_b2;
+    const float *vf_w3, *vf_b3; /* [1][hidden2], [1]   (state value) */
+    const float *log_std;       /* [3] */
+} R6PolicyNet;
+
+size_t r6_policy_net_size(void); /* sizeof(R6PolicyNet) */
+
+/* SB3 `ActorCriticPolicy.forward(obs, deterministic)` followed by the clip to the action Box that
+ * `OnPolicyAlgorithm.collect_rollouts` applies before `env.step`, for n envs in one launch:
+ *   action (n,3)      clipped to [-1,1]: feed it to r6_step          (required)
+ *   raw_action (n,3)  the unclipped sample: what the rollout buffer stores   (NULL to skip)
+ *   value [n], logp [n]  state value, log-probability of raw_action          (NULL to skip)
+ * Gaussian noise: Philox4x32-10 keyed by (seed, step_index, env_offset + i) + Box-Muller, so a rollout
+ * does not depend on sharding; `deterministic` != 0 returns the mean action (`model.predict(...,
+ * deterministic=True)`, montecarlo_script.py).  fp32 arithmetic on the matrix cores (exact-fp32 MFMA). */
+int r6_policy_act(const R6PolicyNet *net, const float *obs, int64_t n, float *action, float *raw_action,
+                  float *value, float *logp, uint64_t seed, uint64_t step_index, uint64_t env_offset,
+                  int deterministic, void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,13 +7,13 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .params import R6Buffers, R6Params
+from .params import R6Buffers, R6Params, R6PolicyNet
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_reset",
-           "r6_observe", "r6_sim_step", "r6_rhs")
+           "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act")
 
 
 class R6Error(RuntimeError):
@@ -49,12 +49,16 @@ def load(path: str | None = None):
     lib.r6_observe.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), vp]
     lib.r6_sim_step.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
     lib.r6_rhs.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
-    for name in ("r6_step", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs"):
+    lib.r6_policy_net_size.restype = C.c_size_t
+    lib.r6_policy_act.argtypes = [C.POINTER(R6PolicyNet), vp, i64, vp, vp, vp, vp, u64, u64, u64, C.c_int, vp]
+    for name in ("r6_step", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act"):
         getattr(lib, name).restype = C.c_int
     if lib.r6_abi_version() != ABI_VERSION:
         raise ImportError(f"libr6dof.so ABI {lib.r6_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     if lib.r6_params_size() != C.sizeof(R6Params) or lib.r6_buffers_size() != C.sizeof(R6Buffers):
         raise ImportError("R6Params/R6Buffers layout mismatch between params.py and libr6dof.so: rebuild")
+    if lib.r6_policy_net_size() != C.sizeof(R6PolicyNet):
+        raise ImportError("R6PolicyNet layout mismatch between params.py and libr6dof.so: rebuild")
     _LIBS[path] = lib
     return lib
 

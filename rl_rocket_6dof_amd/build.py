@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libr6dof.so")
-SOURCES = ["r6_kernels.hip"]
+SOURCES = ["r6_kernels.hip", "r6_policy.hip"]
 HEADERS = ["r6_device.hpp", os.path.join("..", "..", "include", "r6dof.h")]
 ARCH = "gfx950"
 

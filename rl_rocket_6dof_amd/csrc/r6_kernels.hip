@@ -578,6 +578,10 @@ void launch_step_od(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64
 
 extern "C" {
 
+// shared with r6_policy.hip (not part of the public header)
+void r6_internal_set_error(const char* what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
+size_t r6_policy_net_size(void) { return sizeof(R6PolicyNet); }
+
 int r6_abi_version(void) { return R6_ABI_VERSION; }
 size_t r6_params_size(void) { return sizeof(R6Params); }
 size_t r6_buffers_size(void) { return sizeof(R6Buffers); }

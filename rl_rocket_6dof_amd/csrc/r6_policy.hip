@@ -1,0 +1,373 @@
+// Fused actor-critic forward for the rollout loop around Rocket6DOF.step.
+//
+// What it replaces: SB3 1.6 `ActorCriticPolicy.forward(obs)` as called once per env step by
+// `OnPolicyAlgorithm.collect_rollouts` (the reference trains with `PPO("MlpPolicy", env, policy_kwargs=
+// {'net_arch': [128, 64]})`, main_6DOF.py:107-139, and evaluates with `model.predict`,
+// montecarlo_script.py:33-51): two separate tanh MLPs (policy and value), a state-independent log_std,
+// a diagonal Gaussian sample, its log-probability and the action clipped to the Box for `env.step`.
+//
+// One launch: obs (n, od) -> clipped action (n,3), raw sample (n,3), value [n], log-prob [n].
+// In torch this is 6 skinny GEMMs + ~15 elementwise kernels whose (n, 64) intermediates go through HBM
+// (~1 ms at n = 2^20); here the hidden activations never leave registers.
+//
+// Arithmetic: fp32 to ~1e-6.  The GEMMs run on the matrix cores as v_mfma_f32_32x32x16_f16 with every fp32
+// operand split into two halves-precision terms, x = hi + lo (22 significant bits), and three products per
+// K-step, hi*hi + hi*lo + lo*hi, accumulated in fp32.  (The exact-fp32 instruction v_mfma_f32_32x32x2_f32
+// was the first version: it runs at 2x the VALU rate but shares the VALU's issue -- a wave's tanh cannot run
+// under another wave's fp32 MFMAs, measured in scripts/mfma_valu_overlap.hip -- and took 256 us at 2^20.)
+//   out^T[feature][env] = W[feature][k] * act^T[k][env]         (A = weights, B = activations)
+// so that a layer's 32x32 accumulator block -- its column (env) on the lane, its rows (features) in the 16
+// registers -- IS the B operand of the next layer with no LDS round trip and no lane movement: accumulator
+// register r of lane half h holds feature row(r,h) = (r&3) + 8(r>>2) + 4h, and the B fragment of K-step s
+// (16 features) is registers 8s..8s+7 converted in place; the A operand (weights, staged once per workgroup
+// in LDS in exactly that order, already split) supplies W[out][32b + row(8s+j, h)] as element j of lane half
+// h.  The last layer (4 outputs per env) is 128 VALU FMAs per lane plus one cross-half add -- a 32-row MFMA
+// block would be 7/8 padding.
+//
+// Tile = 32 envs per wave (one MFMA column block); weights live in LDS for the whole (persistent) launch.
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/r6dof.h"
+#include "r6_device.hpp"
+
+extern "C" void r6_internal_set_error(const char* what);
+
+namespace r6p {
+
+// Workgroup size per net shape: the LDS weight image is shared by the whole workgroup, so the wider net
+// (83 KB image, one workgroup per CU) runs 768 threads to keep 3 waves per SIMD like the (64,64) net
+// (43 KB image, three 256-thread workgroups per CU).  3 waves/SIMD = a 168-register budget: enough for
+// two layers of accumulators, and what lets one wave's tanh run under another wave's MFMAs.
+template <int H1>
+struct Shape {
+    static constexpr int kBlock = (H1 > 64) ? 768 : 256;
+    static constexpr int kWaves = kBlock / 64;
+};
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with hi, lo in half precision: 22 significant bits of each fp32 value survive
+struct Split {
+    h8 hi, lo;
+};
+__device__ __forceinline__ void split2(float a, float b, h2& hi, h2& lo) {
+    hi = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+}
+__device__ __forceinline__ Split split8(const float (&x)[8]) {
+    Split s;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        h2 hi, lo;
+        split2(x[j], x[j + 1], hi, lo);
+        s.hi[j] = hi[0];
+        s.hi[j + 1] = hi[1];
+        s.lo[j] = lo[0];
+        s.lo[j + 1] = lo[1];
+    }
+    return s;
+}
+// acc += A * B to fp32 accuracy: three half-precision products (lo*lo is below fp32 resolution)
+__device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1): two quarter-rate ops, absolute error ~1e-7 (saturates cleanly)
+__device__ __forceinline__ float tanh_fast(float x) {
+#ifdef R6P_NO_TANH   // timing experiment
+    return fminf(fmaxf(x, -1.0f), 1.0f);
+#endif
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // 2 / ln 2
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// LDS image, H1/H2 = hidden widths (multiples of 32), NET in {0 = pi, 1 = vf}.  Half-precision part
+// (offsets in halves; every fragment = 64 lanes x 8 halves = one ds_read_b128 per lane), hi then lo copy:
+//   w1  [NET][H1/32][64][8]              A of layer 1 (K = 16): lane l, elem j: W1[mb*32 + (l&31)][8(l>>5) + j]
+//                                         (k = od carries the bias against an obs column of ones, the rest is 0)
+//   w2  [NET][H2/32][H1/32][2][64][8]    A of layer 2: lane l, block b, step s, elem j:
+//                                         W2[mb*32 + (l&31)][32b + row(8s + j, l>>5)]
+// fp32 part (offsets in floats, after the half part):
+//   b2  [NET][H2/32][2][16]              accumulator init of layer 2: b2[mb*32 + row(r,h)]
+//   w3  [2 (h)][H2/32][16][4]            last layer: {pi_w3[0..2][32b + row(r,h)], vf_w3[0][32b + row(r,h)]}
+template <int H1, int H2>
+struct Image {
+    static constexpr int kW1 = 2 * (H1 / 32) * 64 * 8;                    // halves per copy
+    static constexpr int kW2 = 2 * (H2 / 32) * (H1 / 32) * 2 * 64 * 8;
+    static constexpr int kHalves = 2 * (kW1 + kW2);                       // hi + lo
+    static constexpr int oW1h = 0, oW1l = kW1, oW2h = 2 * kW1, oW2l = 2 * kW1 + kW2;
+    static constexpr int kB2 = 2 * (H2 / 32) * 2 * 16;
+    static constexpr int kW3 = 2 * (H2 / 32) * 16 * 4;
+    static constexpr int oB2 = kHalves / 2, oW3 = oB2 + kB2, kTotalFloats = oW3 + kW3;   // float offsets
+};
+
+template <int H1, int H2, int OD>
+__global__ __launch_bounds__(Shape<H1>::kBlock, 3) void policy_act_kernel(const R6PolicyNet net, const float* __restrict__ obs, const int64_t n,
+                                                            float* __restrict__ action, float* __restrict__ raw_action,
+                                                            float* __restrict__ value, float* __restrict__ logp,
+                                                            const uint64_t seed, const uint64_t step_index,
+                                                            const uint64_t env_offset, const int deterministic) {
+    using Im = Image<H1, H2>;
+    constexpr int kBlock = Shape<H1>::kBlock, kWaves = Shape<H1>::kWaves;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int col = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kBiasK = OD;   // the obs column that is set to 1 and multiplies b1
+
+    // ---- stage the weights: torch Linear layout [out][in] fp32 -> split halves in fragment order in LDS ----
+    _Float16* ldsh = reinterpret_cast<_Float16*>(lds);
+    auto put_split = [&](int off_hi, int off_lo, int e, float v) __attribute__((always_inline)) {
+        const _Float16 hi = (_Float16)v;
+        ldsh[off_hi + e] = hi;
+        ldsh[off_lo + e] = (_Float16)(v - (float)hi);
+    };
+#pragma unroll 8
+    for (int e = tid; e < Im::kW1; e += kBlock) {
+        const int j = e & 7, l = (e >> 3) & 63, rest = e >> 9;
+        const int mb = rest % (H1 / 32), nt = rest / (H1 / 32);
+        const int k = 8 * (l >> 5) + j;
+        const int m = mb * 32 + (l & 31);
+        const float* w = nt ? net.vf_w1 : net.pi_w1;
+        const float* b = nt ? net.vf_b1 : net.pi_b1;
+        put_split(Im::oW1h, Im::oW1l, e, (k < OD) ? w[m * OD + k] : ((k == kBiasK) ? b[m] : 0.0f));
+    }
+#pragma unroll 8
+    for (int e = tid; e < Im::kW2; e += kBlock) {
+        const int j = e & 7, l = (e >> 3) & 63, sstep = (e >> 9) & 1, rest = e >> 10;
+        const int b = rest % (H1 / 32), mb = (rest / (H1 / 32)) % (H2 / 32), nt = rest / ((H1 / 32) * (H2 / 32));
+        const int k = 32 * b + rowmap(8 * sstep + j, l >> 5);
+        const int m = mb * 32 + (l & 31);
+        const float* w = nt ? net.vf_w2 : net.pi_w2;
+        put_split(Im::oW2h, Im::oW2l, e, w[m * H1 + k]);
+    }
+    for (int e = tid; e < Im::kB2; e += kBlock) {
+        const int r = e & 15, hh = (e >> 4) & 1, rest = e >> 5;
+        const int mb = rest % (H2 / 32), nt = rest / (H2 / 32);
+        const float* b = nt ? net.vf_b2 : net.pi_b2;
+        lds[Im::oB2 + e] = b[mb * 32 + rowmap(r, hh)];
+    }
+    for (int e = tid; e < Im::kW3; e += kBlock) {
+        const int o = e & 3, r = (e >> 2) & 15, rest = e >> 6;
+        const int b = rest % (H2 / 32), hh = rest / (H2 / 32);
+        const int k = 32 * b + rowmap(r, hh);
+        lds[Im::oW3 + e] = (o < 3) ? net.pi_w3[o * H2 + k] : net.vf_w3[k];
+    }
+    __syncthreads();
+
+    const float b3_0 = net.pi_b3[0], b3_1 = net.pi_b3[1], b3_2 = net.pi_b3[2], b3_v = net.vf_b3[0];
+    const float ls0 = net.log_std[0], ls1 = net.log_std[1], ls2 = net.log_std[2];
+
+    const int64_t n_tiles = (n + 31) >> 5;
+    const int64_t nw = (int64_t)gridDim.x * kWaves;
+    // B operand of layer 1: this lane's 8 obs features (k = s + 8h) of env t*32 + col, bias column = 1.
+    // The next tile's features are requested before the current tile is computed (8 registers), so the
+    // ~2 us of load latency sit under ~10 k cycles of matrix-core work instead of in front of them.
+    auto load_x = [&](int64_t tt, float (&xx)[8]) __attribute__((always_inline)) {
+        const int64_t e = tt * 32 + col;
+        const bool in = tt < n_tiles && e < n;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = s + 8 * h;
+            xx[s] = 0.0f;
+            if (k < OD) {
+                if (in) xx[s] = obs[e * OD + k];
+            } else if (k == kBiasK) {
+                xx[s] = 1.0f;
+            }
+        }
+    };
+    float xn[8];
+    load_x((int64_t)blockIdx.x * kWaves + wave, xn);
+#pragma unroll 1
+    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += nw) {
+        const int64_t env = t * 32 + col;
+        const bool live = env < n;
+        const Split xs = split8(xn);
+        load_x(t + nw, xn);
+
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // this lane half's share of (mean0, mean1, mean2, value)
+        // one network at a time (rolled): the two share nothing but x[], and unrolled the scheduler
+        // interleaves them and triples the live registers
+#pragma unroll 1
+        for (int nt = 0; nt < 2; ++nt) {
+            // ---- layer 1: one K = 16 step per 32-feature block, B = the split obs row ---------------------------
+            f32x16 a1[H1 / 32];
+#pragma unroll
+            for (int mb = 0; mb < H1 / 32; ++mb) {
+                const int f = ((nt * (H1 / 32) + mb) * 64 + lane) * 8;
+                const h8 wh = *(const h8*)&ldsh[Im::oW1h + f], wl = *(const h8*)&ldsh[Im::oW1l + f];
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                a1[mb] = mfma3(wh, wl, xs, z);
+            }
+#pragma unroll
+            for (int mb = 0; mb < H1 / 32; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[mb][r] = tanh_fast(a1[mb][r]);
+            }
+
+            // ---- layer 2: accumulators start at the bias; registers 8s..8s+7 of a1[b] are K-step (b, s) ------------
+            f32x16 a2[H2 / 32];
+#pragma unroll
+            for (int mb = 0; mb < H2 / 32; ++mb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b = *(const f32x4*)&lds[Im::oB2 + ((nt * (H2 / 32) + mb) * 2 + h) * 16 + q * 4];
+                    a2[mb][q * 4 + 0] = b[0];
+                    a2[mb][q * 4 + 1] = b[1];
+                    a2[mb][q * 4 + 2] = b[2];
+                    a2[mb][q * 4 + 3] = b[3];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < (H1 / 32) * 2; ++g) {      // g = (b, s)
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = a1[g >> 1][(g & 1) * 8 + j];
+                const Split bs = split8(v);
+#pragma unroll
+                for (int mb = 0; mb < H2 / 32; ++mb) {
+                    const int f = (((nt * (H2 / 32) + mb) * (H1 / 32) * 2 + g) * 64 + lane) * 8;
+                    const h8 wh = *(const h8*)&ldsh[Im::oW2h + f], wl = *(const h8*)&ldsh[Im::oW2l + f];
+                    a2[mb] = mfma3(wh, wl, bs, a2[mb]);
+                }
+                asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
+            }
+
+            // ---- tanh + last layer on the VALU: this half's 16 rows per block ------------------------------
+#pragma unroll
+            for (int mb = 0; mb < H2 / 32; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = tanh_fast(a2[mb][r]);
+                    const f32x4 w3 = *(const f32x4*)&lds[Im::oW3 + ((h * (H2 / 32) + mb) * 16 + r) * 4];
+                    if (nt == 0) {
+                        part[0] = fmaf(w3[0], v, part[0]);
+                        part[1] = fmaf(w3[1], v, part[1]);
+                        part[2] = fmaf(w3[2], v, part[2]);
+                    } else {
+                        part[3] = fmaf(w3[3], v, part[3]);
+                    }
+                }
+            }
+        }
+
+        // ---- the other lane half holds the other 16 rows of every block -------------------------------------
+        const float m0 = part[0] + __shfl_xor(part[0], 32) + b3_0;
+        const float m1 = part[1] + __shfl_xor(part[1], 32) + b3_1;
+        const float m2 = part[2] + __shfl_xor(part[2], 32) + b3_2;
+        const float vv = part[3] + __shfl_xor(part[3], 32) + b3_v;
+
+        // ---- diagonal Gaussian (SB3 DiagGaussianDistribution): sample, log-prob, clip -----------------------
+        if (h == 0 && live) {
+            float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+            if (!deterministic) {
+                const uint64_t gid = env_offset + (uint64_t)env;
+                const r6::U4 w = r6::philox4x32_10(
+                    r6::U4{(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step_index, (uint32_t)(step_index >> 32)},
+                    (uint32_t)seed ^ 0x5851F42Du, (uint32_t)(seed >> 32) ^ 0x4C957F2Du);
+                // Box-Muller on (0,1] uniforms; v_sin/v_cos take their argument in revolutions
+                const float u0 = (float)((w.x >> 8) + 1u) * 5.9604644775390625e-08f;
+                const float u1 = (float)(w.y >> 8) * 5.9604644775390625e-08f;
+                const float u2 = (float)((w.z >> 8) + 1u) * 5.9604644775390625e-08f;
+                const float u3 = (float)(w.w >> 8) * 5.9604644775390625e-08f;
+                const float r01 = sqrtf(-2.0f * __logf(u0)), r23 = sqrtf(-2.0f * __logf(u2));
+                e0 = r01 * __builtin_amdgcn_cosf(u1);
+                e1 = r01 * __builtin_amdgcn_sinf(u1);
+                e2 = r23 * __builtin_amdgcn_cosf(u3);
+            }
+            const float a0 = fmaf(__expf(ls0), e0, m0), a1v = fmaf(__expf(ls1), e1, m1), a2v = fmaf(__expf(ls2), e2, m2);
+            const float lp = -0.5f * (e0 * e0 + e1 * e1 + e2 * e2) - (ls0 + ls1 + ls2) - 2.756815599614018f;   // 1.5 ln(2 pi)
+            if (raw_action) {
+                raw_action[env * 3 + 0] = a0;
+                raw_action[env * 3 + 1] = a1v;
+                raw_action[env * 3 + 2] = a2v;
+            }
+            action[env * 3 + 0] = fminf(fmaxf(a0, -1.0f), 1.0f);
+            action[env * 3 + 1] = fminf(fmaxf(a1v, -1.0f), 1.0f);
+            action[env * 3 + 2] = fminf(fmaxf(a2v, -1.0f), 1.0f);
+            if (value) value[env] = vv;
+            if (logp) logp[env] = lp;
+        }
+    }
+}
+
+template <int H1, int H2, int OD>
+int launch(const R6PolicyNet& net, const float* obs, int64_t n, float* action, float* raw_action, float* value, float* logp,
+           uint64_t seed, uint64_t step_index, uint64_t env_offset, int deterministic, hipStream_t s) {
+    auto kernel = policy_act_kernel<H1, H2, OD>;
+    constexpr int kBlock = Shape<H1>::kBlock, kWaves = Shape<H1>::kWaves;
+    constexpr size_t lds_bytes = sizeof(float) * Image<H1, H2>::kTotalFloats;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+            r6_internal_set_error("r6_policy_act: cannot reserve LDS for the weight image");
+            return R6_E_BADARG;
+        }
+        configured = true;
+    }
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    (void)hipGetLastError();
+    if (std::getenv("R6_DEBUG")) std::fprintf(stderr, "[r6_policy_act] H1=%d H2=%d block=%d lds=%zu B resident/CU=%d CUs=%d\n", H1, H2, kBlock, lds_bytes, per_cu, cus);
+    const int64_t n_tiles = (n + 31) / 32;
+    int64_t blocks = (n_tiles + kWaves - 1) / kWaves;
+    if (blocks > (int64_t)per_cu * cus) blocks = (int64_t)per_cu * cus;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, net, obs, n, action, raw_action, value, logp,
+                       seed, step_index, env_offset, deterministic);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        r6_internal_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+}  // namespace r6p
+
+extern "C" int r6_policy_act(const R6PolicyNet* net, const float* obs, int64_t n, float* action, float* raw_action,
+                             float* value, float* logp, uint64_t seed, uint64_t step_index, uint64_t env_offset,
+                             int deterministic, void* stream) {
+    if (!net || !obs || !action) {
+        r6_internal_set_error("r6_policy_act: net, obs and action are required");
+        return R6_E_BADARG;
+    }
+    if (n < 0 || n >= ((int64_t)1 << 31)) {
+        r6_internal_set_error("r6_policy_act: need 0 <= n < 2^31");
+        return R6_E_BADARG;
+    }
+    if (n == 0) return 0;
+    const R6PolicyNet& p = *net;
+    if (!p.pi_w1 || !p.pi_b1 || !p.pi_w2 || !p.pi_b2 || !p.pi_w3 || !p.pi_b3 || !p.vf_w1 || !p.vf_b1 || !p.vf_w2 || !p.vf_b2 ||
+        !p.vf_w3 || !p.vf_b3 || !p.log_std) {
+        r6_internal_set_error("r6_policy_act: every weight pointer of R6PolicyNet is required");
+        return R6_E_BADARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define R6P_CASE(A, B, D) \
+    if (p.hidden1 == A && p.hidden2 == B && p.obs_dim == D) \
+        return r6p::launch<A, B, D>(p, obs, n, action, raw_action, value, logp, seed, step_index, env_offset, deterministic, s);
+    R6P_CASE(64, 64, 14)
+    R6P_CASE(64, 64, 13)
+    R6P_CASE(128, 64, 14)
+    R6P_CASE(128, 64, 13)
+#undef R6P_CASE
+    r6_internal_set_error("r6_policy_act: supported nets are obs_dim 13|14 with hidden (64,64) or (128,64)");
+    return R6_E_BADARG;
+}

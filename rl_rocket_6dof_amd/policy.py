@@ -1,0 +1,82 @@
+"""Fused actor-critic forward for rollouts: ``r6_policy_act`` behind an SB3-shaped ``forward``.
+
+``FusedActorCritic(policy)`` wraps a ``ppo.ActorCritic`` (the SB3 1.6 ``MlpPolicy`` the reference trains,
+main_6DOF.py:107-139) and evaluates it for N envs in ONE HIP launch -- both tanh MLPs on the matrix cores in
+exact fp32, hidden activations in registers, Gaussian sample + log-probability + Box clip in the epilogue --
+instead of ~20 torch kernels whose (N, 64) intermediates go through HBM.  The torch module stays the owner
+of the weights (the kernel reads the parameter tensors in place), so an optimiser step is visible to the
+next ``forward`` without any copy.  No CPU path: needs the HIP library and a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .params import R6PolicyNet
+
+SUPPORTED_ARCHS = ((64, 64), (128, 64))
+
+
+def _linears(seq):
+    return [m for m in seq if isinstance(m, torch.nn.Linear)]
+
+
+class FusedActorCritic:
+    def __init__(self, policy, seed: int = 0, env_offset: int = 0, lib_path: Optional[str] = None):
+        self.lib = _lib.load(lib_path)
+        self.policy = policy
+        pi, vf = _linears(policy.pi), _linears(policy.vf)
+        if len(pi) != 3 or len(vf) != 3:
+            raise ValueError("the fused forward supports two hidden layers per network")
+        self.obs_dim = pi[0].in_features
+        arch = (pi[0].out_features, pi[1].out_features)
+        if arch not in SUPPORTED_ARCHS or (vf[0].out_features, vf[1].out_features) != arch or self.obs_dim not in (13, 14):
+            raise ValueError(f"supported: obs_dim 13|14, hidden {SUPPORTED_ARCHS}; got obs_dim {self.obs_dim}, hidden {arch}")
+        if pi[2].out_features != 3 or vf[2].out_features != 1:
+            raise ValueError("expected a 3-dim action head and a scalar value head")
+        self._params = [pi[0].weight, pi[0].bias, pi[1].weight, pi[1].bias, pi[2].weight, pi[2].bias,
+                        vf[0].weight, vf[0].bias, vf[1].weight, vf[1].bias, vf[2].weight, vf[2].bias, policy.log_std]
+        for t in self._params:
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("policy parameters must be contiguous float32 CUDA tensors")
+        self.device = self._params[0].device
+        self.arch = arch
+        self.seed, self.env_offset = int(seed), int(env_offset)
+        self._calls = 0
+
+    def _net(self) -> R6PolicyNet:
+        # rebuilt per call: optimisers update parameters in place, but .data_ptr() is what the launch needs
+        net = R6PolicyNet()
+        net.obs_dim, net.hidden1, net.hidden2 = self.obs_dim, self.arch[0], self.arch[1]
+        names = ("pi_w1", "pi_b1", "pi_w2", "pi_b2", "pi_w3", "pi_b3", "vf_w1", "vf_b1", "vf_w2", "vf_b2", "vf_w3", "vf_b3", "log_std")
+        for name, t in zip(names, self._params):
+            setattr(net, name, t.data_ptr())
+        return net
+
+    @torch.no_grad()
+    def forward(self, obs: torch.Tensor, deterministic: bool = False, step_index: Optional[int] = None,
+                out: Optional[Tuple[torch.Tensor, ...]] = None):
+        """Returns ``(clipped_actions (N,3), raw_actions (N,3), values (N,), log_probs (N,))``.
+        ``step_index`` keys the noise stream (defaults to an internal call counter); ``out`` reuses buffers."""
+        if obs.device != self.device or obs.dtype != torch.float32 or not obs.is_contiguous() or obs.dim() != 2 \
+                or obs.shape[1] != self.obs_dim:
+            raise ValueError(f"obs must be a contiguous float32 (N, {self.obs_dim}) tensor on {self.device}")
+        n = obs.shape[0]
+        if out is None:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            out = (torch.empty((n, 3), **f32), torch.empty((n, 3), **f32), torch.empty((n,), **f32), torch.empty((n,), **f32))
+        act, raw, val, logp = out
+        self._calls += 1
+        step = self._calls if step_index is None else int(step_index)
+        net = self._net()
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_policy_act(C.byref(net), obs.data_ptr(), n, act.data_ptr(), raw.data_ptr(), val.data_ptr(),
+                                        logp.data_ptr(), self.seed, step, self.env_offset, int(bool(deterministic)),
+                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        _lib.check(rc, "r6_policy_act")
+        return act, raw, val, logp
+
+    __call__ = forward

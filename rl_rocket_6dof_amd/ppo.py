@@ -50,6 +50,8 @@ class PPOConfig:
     net_arch: Sequence[int] = (64, 64)   # SB3 MlpPolicy default; the reference's training run used [128, 64]
     log_std_init: float = 0.0
     seed: int = 42
+    fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
+                                     # net shape is supported and the env is on a GPU; torch modules otherwise
 
 
 def _mlp(sizes, out_dim, out_gain):
@@ -134,6 +136,20 @@ class PPO:
         self.buf_done = torch.zeros((T, n), **f32)
         self._obs = None
         self.num_timesteps = 0
+        self.fused = None
+        self._rollout_step = 0
+        if cfg.fused_policy and self.device.type == "cuda":
+            from .policy import FusedActorCritic
+
+            if self._fusable() and env.obs_dim in (13, 14):
+                self.fused = FusedActorCritic(self.policy, seed=cfg.seed, env_offset=getattr(env, "env_offset", 0))
+                self._act_clip = torch.zeros((n, 3), **f32)
+
+    def _fusable(self) -> bool:
+        from .policy import SUPPORTED_ARCHS
+
+        lin = [m for m in self.policy.pi if isinstance(m, nn.Linear)]
+        return len(lin) == 3 and (lin[0].out_features, lin[1].out_features) in SUPPORTED_ARCHS
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -142,12 +158,20 @@ class PPO:
         if self._obs is None:
             self._obs = env.reset().clone()
         for t in range(cfg.n_steps):
-            actions, values, logp = self.policy.act(self._obs, generator=self.gen)
             self.buf_obs[t].copy_(self._obs)
-            self.buf_act[t].copy_(actions)
-            self.buf_val[t].copy_(values)
-            self.buf_logp[t].copy_(logp)
-            obs, rew, done, _ = env.step(actions.clamp(-1.0, 1.0).contiguous())   # SB3 clips to the Box
+            if self.fused is not None:
+                # one launch: sample, log-prob, value and the Box clip, written straight into the rollout buffer
+                self._rollout_step += 1
+                self.fused(self.buf_obs[t], step_index=self._rollout_step,
+                           out=(self._act_clip, self.buf_act[t], self.buf_val[t], self.buf_logp[t]))
+                clipped = self._act_clip
+            else:
+                actions, values, logp = self.policy.act(self._obs, generator=self.gen)
+                self.buf_act[t].copy_(actions)
+                self.buf_val[t].copy_(values)
+                self.buf_logp[t].copy_(logp)
+                clipped = actions.clamp(-1.0, 1.0).contiguous()                  # SB3 clips to the Box
+            obs, rew, done, _ = env.step(clipped)
             rew = rew.clone()
             if env.max_episode_steps and env.flags is not None and env.final_obs is not None:
                 trunc = (env.flags & FLAG_TRUNCATED) != 0          # TimeLimit.truncated -> bootstrap
