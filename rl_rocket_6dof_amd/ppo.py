@@ -208,7 +208,9 @@ class PPO:
         old_logp, old_val = self.buf_logp.reshape(total), self.buf_val.reshape(total)
         adv, ret = self.adv.reshape(total), self.ret.reshape(total)
         bs = min(cfg.batch_size, total)
-        stats = dict(pg_loss=0.0, v_loss=0.0, entropy=0.0, clip_frac=0.0, approx_kl=0.0, n=0)
+        keys = ("pg_loss", "v_loss", "entropy", "clip_frac", "approx_kl")
+        acc = torch.zeros(len(keys), dtype=torch.float32, device=self.device)   # summed on the device: no per-batch sync
+        n_batches = 0
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(total, device=self.device, generator=self.gen)
             for s in range(0, total - bs + 1, bs):
@@ -228,14 +230,11 @@ class PPO:
                 torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
                 self.opt.step()
                 with torch.no_grad():
-                    stats["pg_loss"] += float(pg)
-                    stats["v_loss"] += float(v_loss)
-                    stats["entropy"] += float(-ent)
-                    stats["clip_frac"] += float(((ratio - 1).abs() > cfg.clip_range).float().mean())
-                    stats["approx_kl"] += float(((ratio - 1) - (logp - old_logp[mb])).mean())
-                    stats["n"] += 1
-        k = max(stats.pop("n"), 1)
-        return {key: v / k for key, v in stats.items()}
+                    acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
+                                        ((ratio - 1) - (logp - old_logp[mb])).mean()])
+                    n_batches += 1
+        out = (acc / max(n_batches, 1)).tolist()
+        return dict(zip(keys, out))
 
     def learn(self, total_timesteps: int, log=None):
         """Alternates rollouts and updates until ``total_timesteps`` env steps (whole job) are done.
