@@ -50,19 +50,55 @@ class PPOConfig:
     net_arch: Sequence[int] = (64, 64)   # SB3 MlpPolicy default; the reference's training run used [128, 64]
     log_std_init: float = 0.0
     seed: int = 42
+    graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
     fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
                                      # net shape is supported and the env is on a GPU; torch modules otherwise
+
+
+class _TallLinearFn(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is a hand-split-K product.  In a PPO minibatch of 2^20 samples the
+    weight gradient is a (64 x 2^20) @ (2^20 x 64) GEMM; the BLAS heuristics give it one tile column and
+    1.5 ms (2.0 ms for the 3-row head), a batched product over 256 row chunks + a sum takes 0.11 ms
+    (scripts/gemm_probe.py).  Forward and input gradient are the plain GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        rows = x.shape[0]
+        c = 256
+        while c > 1 and (rows % c or rows // c < 512):
+            c //= 2
+        if c > 1:
+            gw = torch.bmm(g.reshape(c, rows // c, -1).transpose(1, 2), x.reshape(c, rows // c, -1)).sum(0)
+        else:
+            gw = g.t() @ x
+        return gx, gw, g.sum(0)
+
+
+class TallLinear(nn.Linear):
+    """``nn.Linear`` (same parameters, same state_dict) for tall inputs, see ``_TallLinearFn``."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= 1 << 15 and x.is_cuda and torch.is_grad_enabled():
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 def _mlp(sizes, out_dim, out_gain):
     layers, last = [], sizes[0]
     for h in sizes[1:]:
-        lin = nn.Linear(last, h)
+        lin = TallLinear(last, h)
         nn.init.orthogonal_(lin.weight, gain=math.sqrt(2))
         nn.init.zeros_(lin.bias)
         layers += [lin, nn.Tanh()]
         last = h
-    head = nn.Linear(last, out_dim)
+    head = TallLinear(last, out_dim)
     nn.init.orthogonal_(head.weight, gain=out_gain)
     nn.init.zeros_(head.bias)
     return nn.Sequential(*layers, head)
@@ -123,7 +159,9 @@ class PPO:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         torch.manual_seed(cfg.seed)          # identical initial weights on every rank
         self.policy = (policy or ActorCritic(env.obs_dim, 3, cfg.net_arch, cfg.log_std_init)).to(self.device)
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5)
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
+                                    capturable=(self.device.type == "cuda" and cfg.graph_update))
+        self._graph, self._graph_key, self._eager_steps = None, None, 0
         rank = dist.get_rank() if self.world > 1 else 0
         self.gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1000003 * rank)
         n, T = env.num_envs, cfg.n_steps
@@ -134,6 +172,8 @@ class PPO:
         self.buf_val = torch.zeros((T, n), **f32)
         self.buf_rew = torch.zeros((T, n), **f32)
         self.buf_done = torch.zeros((T, n), **f32)
+        self.adv = torch.zeros((T, n), **f32)
+        self.ret = torch.zeros((T, n), **f32)
         self._obs = None
         self.num_timesteps = 0
         self.fused = None
@@ -183,7 +223,9 @@ class PPO:
             self._obs = obs.clone()           # env.obs is overwritten by the next step
         self.num_timesteps += cfg.n_steps * env.num_envs * self.world
         last_values = self.policy.value(self._obs)
-        self.adv, self.ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done, last_values, cfg.gamma, cfg.gae_lambda)
+        adv, ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done, last_values, cfg.gamma, cfg.gae_lambda)
+        self.adv.copy_(adv)      # persistent buffers: the graphed update step reads these addresses
+        self.ret.copy_(ret)
 
     def _sync_grads(self):
         if self.world == 1:
@@ -199,40 +241,69 @@ class PPO:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
+    def _minibatch_step(self, mb, flat, acc):
+        """One SB3 ``PPO.train`` minibatch: loss, backward, (all-reduce), grad-norm clip, Adam; stats into ``acc``."""
+        cfg = self.cfg
+        obs, act, old_logp, adv, ret = flat
+        a = adv[mb]
+        if cfg.normalize_advantage and mb.numel() > 1:
+            a = (a - a.mean()) / (a.std() + 1e-8)
+        values, logp, entropy = self.policy.evaluate(obs[mb], act[mb])
+        ratio = torch.exp(logp - old_logp[mb])
+        pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+        v_loss = torch.nn.functional.mse_loss(ret[mb], values)
+        ent = -entropy.mean()
+        loss = pg + cfg.ent_coef * ent + cfg.vf_coef * v_loss
+        self.opt.zero_grad(set_to_none=False)
+        loss.backward()
+        self._sync_grads()
+        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
+        self.opt.step()
+        with torch.no_grad():
+            acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
+                                ((ratio - 1) - (logp - old_logp[mb])).mean()])
+
+    def _graphed_step(self, flat, bs):
+        """The minibatch step captured once into a HIP graph (static index / stats buffers) and replayed: at
+        minibatches of <= 2^17 samples the ~250 kernels of a step are launch-bound in eager mode (2.1 ms per
+        step at 65 536 samples against ~0.4 ms of GPU work).  Single-process only (no collective inside)."""
+        key = (bs,) + tuple(t.data_ptr() for t in flat)
+        if self._graph is not None and self._graph_key == key:
+            return self._graph
+        self._mb_idx = torch.zeros(bs, dtype=torch.int64, device=self.device)
+        self._acc = torch.zeros(5, dtype=torch.float32, device=self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._minibatch_step(self._mb_idx, flat, self._acc)
+        self._graph_key = key
+        return self._graph
+
     def train(self) -> Dict[str, float]:
         cfg = self.cfg
         T, n = self.buf_rew.shape
         total = T * n
-        obs = self.buf_obs.reshape(total, -1)
-        act = self.buf_act.reshape(total, 3)
-        old_logp, old_val = self.buf_logp.reshape(total), self.buf_val.reshape(total)
-        adv, ret = self.adv.reshape(total), self.ret.reshape(total)
+        flat = (self.buf_obs.reshape(total, -1), self.buf_act.reshape(total, 3), self.buf_logp.reshape(total),
+                self.adv.reshape(total), self.ret.reshape(total))
         bs = min(cfg.batch_size, total)
         keys = ("pg_loss", "v_loss", "entropy", "clip_frac", "approx_kl")
+        use_graph = cfg.graph_update and self.device.type == "cuda" and self.world == 1 and bs <= (1 << 17)
         acc = torch.zeros(len(keys), dtype=torch.float32, device=self.device)   # summed on the device: no per-batch sync
         n_batches = 0
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(total, device=self.device, generator=self.gen)
             for s in range(0, total - bs + 1, bs):
                 mb = perm[s:s + bs]
-                a = adv[mb]
-                if cfg.normalize_advantage and bs > 1:
-                    a = (a - a.mean()) / (a.std() + 1e-8)
-                values, logp, entropy = self.policy.evaluate(obs[mb], act[mb])
-                ratio = torch.exp(logp - old_logp[mb])
-                pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
-                v_loss = torch.nn.functional.mse_loss(ret[mb], values)
-                ent = -entropy.mean()
-                loss = pg + cfg.ent_coef * ent + cfg.vf_coef * v_loss
-                self.opt.zero_grad(set_to_none=False)
-                loss.backward()
-                self._sync_grads()
-                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
-                self.opt.step()
-                with torch.no_grad():
-                    acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
-                                        ((ratio - 1) - (logp - old_logp[mb])).mean()])
-                    n_batches += 1
+                if use_graph and self._eager_steps >= 3:      # the first steps run eagerly (allocator / Adam state warm-up)
+                    g = self._graphed_step(flat, bs)
+                    self._mb_idx.copy_(mb)
+                    g.replay()
+                else:
+                    self._minibatch_step(mb, flat, acc)
+                    self._eager_steps += 1
+                n_batches += 1
+        if use_graph and self._graph is not None:
+            acc += self._acc
+            self._acc.zero_()
         out = (acc / max(n_batches, 1)).tolist()
         return dict(zip(keys, out))
 

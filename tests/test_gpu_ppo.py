@@ -24,3 +24,47 @@ def test_ppo_improves_return_on_the_real_env():
           f"ep_len_mean {hist[-1]['ep_len_mean']:.0f}")
     assert late > early + 10.0 and late > -20.0
     assert env.obs.shape == (8192, 13) and bool(torch.isfinite(env.obs).all())
+
+
+@pytest.mark.gpu
+def test_tall_linear_gradients_match_plain_linear():
+    """The split-K weight gradient of ppo.TallLinear against torch.nn.Linear on the same data."""
+    import torch
+
+    from rl_rocket_6dof_amd.ppo import TallLinear
+
+    torch.manual_seed(0)
+    for rows, fin, fout in ((1 << 17, 64, 64), (1 << 16, 14, 128), (98304, 64, 3)):
+        ref = torch.nn.Linear(fin, fout).cuda()
+        tall = TallLinear(fin, fout).cuda()
+        tall.load_state_dict(ref.state_dict())
+        x = torch.randn(rows, fin, device="cuda")
+        x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        w = torch.randn(rows, fout, device="cuda") / rows
+        (ref(x1) * w).sum().backward()
+        (tall(x2) * w).sum().backward()
+        for a, b in ((x1.grad, x2.grad), (ref.weight.grad, tall.weight.grad), (ref.bias.grad, tall.bias.grad)):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_graphed_update_follows_the_eager_update():
+    """The HIP-graph replay of the minibatch step must read every rollout's fresh advantages / returns (a
+    captured pointer to a stale tensor trains on old data): three iterations, graph on vs off, same seeds ->
+    the same parameters up to fp32 reduction order."""
+    import torch
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+    from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+    out = []
+    for graph in (False, True):
+        env = BatchedRocket6DOF(4096, default_env_config(), remove_mass=True, clip_reward=(-1, 100),
+                                max_episode_steps=1500, seed=3)
+        algo = PPO(env, PPOConfig(n_steps=16, batch_size=1 << 13, n_epochs=2, net_arch=(64, 64), seed=3, graph_update=graph))
+        hist = algo.learn(3 * 16 * 4096)
+        assert (algo._graph is not None) == graph
+        out.append((torch.cat([p.detach().reshape(-1) for p in algo.policy.parameters()]), hist[-1]))
+    pe, pg = out[0][0], out[1][0]
+    assert float((pe - pg).abs().max()) < 2e-3, float((pe - pg).abs().max())
+    for k in ("pg_loss", "v_loss", "approx_kl"):
+        assert abs(out[0][1][k] - out[1][1][k]) <= 2e-2 * max(1.0, abs(out[0][1][k])), (k, out[0][1][k], out[1][1][k])
