@@ -5,7 +5,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 // (a) our access pattern: per lane 14+1 dword loads (SoA), 3 action dwords, 14 dword stores, reward, done byte, obs via LDS float4
 __global__ __launch_bounds__(256) void k_pattern(const float* st, float* st_out, const float* ep, const float* act, float* obs,
-                                                 float* rew, uint8_t* done, int64_t n, int64_t ld) {
+                                                 float* rew, uint8_t* done, int64_t n, int64_t ld, int tiled) {
     __shared__ __attribute__((aligned(16))) float tiles[4][64 * 14];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tile = tiles[wave];
@@ -13,8 +13,10 @@ __global__ __launch_bounds__(256) void k_pattern(const float* st, float* st_out,
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < nt; t += nw) {
         const int64_t e0 = t * 64;
         float y[14];
+        // tiled != 0: state as [tile][14][64] (a tile's 14 row segments contiguous) instead of SoA [14][ld]
+        const int64_t sbase = tiled ? e0 * 14 : e0, sstride = tiled ? 64 : ld;
 #pragma unroll
-        for (int j = 0; j < 14; ++j) y[j] = st[j * ld + e0 + lane];
+        for (int j = 0; j < 14; ++j) y[j] = st[j * sstride + sbase + lane];
         const float m0 = ep[e0 + lane];
         const float a0 = act[(e0 + lane) * 3], a1 = act[(e0 + lane) * 3 + 1], a2 = act[(e0 + lane) * 3 + 2];
 #pragma unroll
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(256) void k_pattern(const float* st, float* st_out,
         rew[e0 + lane] = m0 + a1 + a2;
         done[e0 + lane] = (y[0] > 1e30f) ? 1 : 0;
 #pragma unroll
-        for (int j = 0; j < 14; ++j) st_out[j * ld + e0 + lane] = y[j];
+        for (int j = 0; j < 14; ++j) st_out[j * sstride + sbase + lane] = y[j];
 #pragma unroll
         for (int j = 0; j < 14; ++j) tile[lane * 14 + j] = y[j] * 0.5f;
         __builtin_amdgcn_wave_barrier();
@@ -49,8 +51,8 @@ __global__ __launch_bounds__(256) void k_copy2(const f4* in, f4* out, int64_t n4
 }
 extern "C" {
 int mb_pattern(const float* st, float* st_out, const float* ep, const float* act, float* obs, float* rew, uint8_t* done,
-               int64_t n, int64_t ld, int blocks, void* s) {
-    hipLaunchKernelGGL(k_pattern, dim3(blocks), dim3(256), 0, (hipStream_t)s, st, st_out, ep, act, obs, rew, done, n, ld);
+               int64_t n, int64_t ld, int blocks, void* s, int tiled) {
+    hipLaunchKernelGGL(k_pattern, dim3(blocks), dim3(256), 0, (hipStream_t)s, st, st_out, ep, act, obs, rew, done, n, ld, tiled);
     return (int)hipGetLastError();
 }
 int mb_copy(const void* in, void* out, int64_t n_in4, int64_t n_out4, int blocks, void* s) {
