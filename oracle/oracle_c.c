@@ -175,7 +175,9 @@ static double tgo_quartic(double a, double c, double d, double e) {
         double p = ((t * t + b2) * t + b1) * t + b0, dp = (4 * t * t + 2 * b2) * t + b1;
         if (!left) {
             if (p <= 0) left = 1;
-            else if (dp <= 0 || t < ti) { left = 1; t = 0; continue; }
+            /* leaving the convex branch (t > ti) with p > 0 -- by a non-positive slope or by a Newton step
+               that lands left of the inflection point -- proves it holds no root: restart from 0 */
+            else if (dp <= 0 || t < ti || t - p / dp < ti) { left = 1; t = 0; continue; }
         }
         if (!(dp > 0)) break;
         double tn = t - p / dp;

@@ -588,15 +588,18 @@ __device__ __forceinline__ void quartic_newton_safe(const Quartic& q, float& t, 
     const float t2 = t * t;
     const float p = fmaf(fmaf(t2 + q.b2, t, q.b1), t, q.b0);
     const float dp = fmaf(fmaf(4.0f, t2, 2.0f * q.b2), t, q.b1);
-    if (allow_restart && !left && p > 0.0f && (dp <= 0.0f || t < q.ti)) {
-        left = true;  // fell off the convex branch without meeting a root: restart on the concave one
+    const float step = (dp > 0.0f) ? p * frcp(dp) : 0.0f;
+    float tn = t - step;
+    // On the convex branch (t > ti) a Newton iterate taken right of a root stays right of it, so an iterate
+    // that leaves the branch -- slope <= 0, or a step that lands left of the inflection point, e.g. from the
+    // nearly flat bottom of a positive minimum -- proves the branch holds no root: restart on the concave one.
+    if (allow_restart && !left && p > 0.0f && (dp <= 0.0f || t < q.ti || tn < q.ti)) {
+        left = true;
         t = 0.0f;
         conv = false;
         return;
     }
     left = left || (p <= 0.0f);                      // at / left of the root: finish from the left
-    const float step = (dp > 0.0f) ? p * frcp(dp) : 0.0f;
-    float tn = t - step;
     tn = left ? fmaxf(tn, t) : fminf(tn, t);          // monotone (guards round-off)
     conv = fabsf(tn - t) <= 2e-7f * fabsf(tn);
     t = tn;
@@ -655,7 +658,20 @@ __device__ __forceinline__ float t_go_quartic(float c2, float c1, float c0) {
     const double pd = fma(fma(fma((double)g2 * td, td, (double)c2), td, (double)c1), td, (double)c0);
     const float dpf = fmaf(fmaf(4.0f * g2, t * t, 2.0f * c2), t, c1);
     const float corr = (float)pd * frcp(dpf);
-    return (dpf > 0.0f) ? t - corr : t;
+    if (!(dpf > 0.0f)) return t;
+    // An ill-conditioned root (next to the local maximum: p' small) is still ~1e-5 off after one correction;
+    // such lanes -- a few per million -- take two more Newton steps entirely in fp64 (wave-uniform branch).
+    if (__builtin_expect(__any(fabsf(corr) > 2e-6f * t), 0)) {
+        double x = td - (double)corr;
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {
+            const double px = fma(fma(fma((double)g2 * x, x, (double)c2), x, (double)c1), x, (double)c0);
+            const double dx = fma(fma(4.0 * (double)g2 * x, x, 2.0 * (double)c2), x, (double)c1);
+            if (dx > 0.0) x -= px / dx;
+        }
+        return (fabsf(corr) > 2e-6f * t) ? (float)x : t - corr;
+    }
+    return t - corr;
 }
 
 struct RewardOut {

@@ -179,3 +179,62 @@ def test_mass_termination_overflows_the_reset_queue(torch_cuda, cfg):
         np.testing.assert_allclose(a[i, 6:10], want[6:10], rtol=0, atol=1.2e-7)
     np.testing.assert_allclose(obs.cpu().numpy()[::4097], a[::4097] / P.normalizer, rtol=3e-7, atol=1e-9)
     assert not torch.equal(before, after)
+
+
+@pytest.mark.parametrize("integ,shaping", [("rk4", "acceleration"), ("euler", "velocity")])
+def test_fuzz_wide_state_ranges_vs_c_oracle(torch_cuda, cfg, integ, shaping):
+    """One step from 200 000 states drawn far outside the distribution of the golden rollouts (whole bounds box
+    and beyond, |v| up to 300 m/s, arbitrary attitudes, |omega| up to 1 rad/s, 25-45 t, actions in [-1.5, 1.5]
+    -- the env does not clip) against the C oracle: post-state / obs within 1e-5 of the normaliser scale, done
+    and flag bytes equal, reward within 1e-5 -- except for the few draws that sit on a discrete threshold
+    (a float32 vs float64 straddle flips a whole reward term there), which are counted and bounded."""
+    torch = torch_cuda
+    import json
+
+    from oracle import oracle_c as oc
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    c2 = json.loads(json.dumps(cfg))
+    c2["reward_shaping_type"] = shaping
+    if shaping == "velocity":
+        c2["landing_params"]["waypoint"] = 40
+    n = 200_000
+    rng = np.random.default_rng(11)
+    P = onp.OracleParams.from_config(c2)
+    s = np.zeros((n, 14))
+    s[:, 0] = rng.uniform(-50.0, 2600.0, n)
+    s[: n // 4, 0] = rng.uniform(0.0, 12.0, n // 4)            # a quarter close to the ground: events, landing terms
+    s[:, 1:3] = rng.uniform(-2600.0, 2600.0, (n, 2))
+    s[: n // 4, 1:3] = rng.uniform(-60.0, 60.0, (n // 4, 2))
+    s[:, 3:6] = rng.uniform(-300.0, 300.0, (n, 3))
+    s[: n // 4, 3:6] = rng.uniform(-25.0, 25.0, (n // 4, 3))
+    q = rng.normal(size=(n, 4))
+    s[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    s[:, 10:13] = rng.uniform(-1.0, 1.0, (n, 3))
+    s[:, 13] = rng.uniform(25e3, 45e3, n)
+    s = s.astype(np.float32).astype(np.float64)
+    m0 = (s[:, 13] + rng.uniform(0.0, 3e3, n)).astype(np.float32).astype(np.float64)
+    a = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+
+    env = BatchedRocket6DOF(n, c2, integrator=integ, auto_reset=False, record_flags=True, seed=1)
+    env.set_state(torch.as_tensor(s, dtype=torch.float32), m0=torch.as_tensor(m0, dtype=torch.float32))
+    obs, rew, done, _ = env.step(torch.as_tensor(a))
+    ref = oc.BatchOracle(n, c2, integrator=integ)
+    ref.set_state(s, m0=m0)
+    ref.step(a)
+
+    post = env.get_state().cpu().numpy().astype(np.float64)
+    assert np.isfinite(post).all()
+    err = np.abs(post - ref.state) / np.maximum(np.abs(ref.state), P.normalizer)
+    assert err.max() < 1e-5, f"post-state: worst scaled error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    eo = np.abs(obs.cpu().numpy() - ref.obs) / np.maximum(np.abs(ref.obs), 1.0)
+    assert eo.max() < 1e-5
+    d_bad = int((done.cpu().numpy() != ref.done.astype(bool)).sum())
+    f_bad = int(((env.flags.cpu().numpy() & 3) != (ref.flags & 3)).sum())
+    r = rew.cpu().numpy().astype(np.float64)
+    r_bad = int((np.abs(r - ref.reward) > 1e-5 * np.maximum(np.abs(ref.reward), 1.0)).sum())
+    print(f"[fuzz {integ}/{shaping}] state err {err.max():.2e}, obs err {eo.max():.2e}, mismatches: done {d_bad}, flags {f_bad}, "
+          f"reward {r_bad} of {n}; ground events {int((ref.flags & 1).sum())}, bounds {int(((ref.flags >> 1) & 1).sum())}")
+    assert d_bad <= 2 and f_bad <= 2, "done / flag bytes differ on more than a threshold straddle"
+    assert r_bad <= n // 5000, "reward differs beyond tolerance on more envs than threshold straddles explain"

@@ -99,3 +99,43 @@ def test_auto_reset_and_counters(cfg):
         assert np.all(env.reward <= 100) and np.all(env.reward >= -1)
     assert env.done.all() and ((env.flags & 4) != 0).sum() > n // 2     # TimeLimit at step 30
     assert np.all(env.ep_step == 0) and np.all(env.ep_return == 0)      # everything was just reset
+
+
+def test_quartic_t_go_against_np_roots_on_wide_ranges(cfg, P):
+    """rocket_env.py:528-546 picks the first positive real entry of np.roots.  The Newton solvers of the C
+    oracle (and of the HIP kernel) must find that root also where the quartic has a positive minimum right of
+    it (a complex pair with positive real part): from the nearly flat bottom of that minimum a Newton step
+    jumps far to the left, which is the signal to restart on the other branch (a solver without that rule
+    fails on 0.05 % of the second family below; a GPU-vs-C fuzz run found the first cases).  Families: wide
+    uniform states, and fast approaches (v nearly anti-parallel to r, |v| = 2-25 % of |r| per second)."""
+    rng = np.random.default_rng(5)
+    n1, n2 = 6_000, 60_000
+    n = n1 + n2
+    s = np.zeros((n, 14))
+    s[:, 6] = 1.0
+    s[:, 13] = rng.uniform(25e3, 45e3, n)
+    s[:n1, 0] = rng.uniform(0.0, 2600.0, n1)
+    s[:n1, 1:3] = rng.uniform(-2600.0, 2600.0, (n1, 2))
+    s[:n1, 3:6] = rng.uniform(-300.0, 300.0, (n1, 3))
+    d = rng.normal(size=(n2, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rmag = rng.uniform(500.0, 4000.0, n2)
+    s[n1:, 0:3] = d * rmag[:, None]
+    s[n1:, 3:6] = -d * (rmag * rng.uniform(0.02, 0.25, n2))[:, None] + rng.normal(size=(n2, 3)) * 20.0
+    s = s.astype(np.float32).astype(np.float64)
+    a = np.zeros((n, 3), np.float32)
+    env = oc.BatchOracle(n, cfg, dt=1e-9)
+    env.set_state(s)
+    env.step(a)
+    u = onp.denormalize_action(a[0])
+    worst, n_pair = 0.0, 0
+    for i in range(n):
+        s32 = s[i].astype(np.float32)
+        want = onp.reward_terms(s32, u, s[i][6:10], P)[0]
+        worst = max(worst, abs(env.terms[i, 0] - want) / max(abs(want), 1e-2))
+        if i % 50 == 0:
+            r, v = s32[0:3], s32[3:6]
+            roots = np.roots([9.81 ** 2, 0.0, -4.0 * float(v @ v), -24.0 * float(r @ v), -36.0 * float(r @ r)])
+            n_pair += int(any(z.imag > 0 and z.real > 0 for z in roots))
+    assert n_pair > 100, "the sample must contain quartics with a complex pair right of the root"
+    assert worst < 5e-6, f"tracking term differs from the np.roots restatement: {worst:.3e}"
