@@ -537,3 +537,54 @@ def test_quartic_near_double_root_family_vs_c_oracle(torch_cuda, cfg):
     # within 1 %): there t_go moves by 1e-4 with one ulp of the reference's own float32 r.v product, and the
     # three implementations (np.roots / C / HIP) scatter by that much among themselves -- a few per million.
     assert bad <= 10 and err.max() < 2e-4, f"tracking term: {bad} states beyond 1e-5, worst {err.max():.3e} at {int(err.argmax())}"
+
+
+def test_rk45_fuzz_vs_scipy_oracle(torch_cuda, cfg, P):
+    """integrator="rk45" on 1500 states far outside the golden distribution (fast tumbling, any attitude,
+    ground contact within the step, dt = 0.1 and 0.5) against the numpy/scipy restatement of simulator.py:83-88
+    (solve_ivp RK45 + terminal event).  fp32 step control follows scipy's accept/reject decisions except on
+    borderline error norms, so: status equal, state within 1e-4 of the normaliser scale everywhere and within
+    1e-5 on at least 99 % of the states; nfev equal on at least 90 %."""
+    torch = torch_cuda
+    import json
+
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    for dt in (0.1, 0.5):
+        c2 = json.loads(json.dumps(cfg))
+        c2["timestep"] = dt
+        P2 = onp.OracleParams.from_config(c2)
+        rng = np.random.default_rng(int(dt * 10))
+        n = 750
+        s = np.zeros((n, 14))
+        s[:, 0] = rng.uniform(5.0, 2500.0, n)
+        s[: n // 3, 0] = rng.uniform(0.1, 20.0, n // 3)
+        s[:, 1:3] = rng.uniform(-2000.0, 2000.0, (n, 2))
+        s[:, 3:6] = rng.uniform(-200.0, 200.0, (n, 3))
+        s[: n // 3, 3] = rng.uniform(-60.0, 5.0, n // 3)
+        q = rng.normal(size=(n, 4))
+        s[:, 6:10] = q / np.linalg.norm(q, axis=1, keepdims=True)
+        s[:, 10:13] = rng.uniform(-0.8, 0.8, (n, 3))
+        s[:, 13] = rng.uniform(25e3, 45e3, n)
+        s = s.astype(np.float32)
+        m0 = (s[:, 13] + rng.uniform(0.0, 2e3, n).astype(np.float32)).astype(np.float32)
+        a = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+        env = BatchedRocket6DOF(n, c2, integrator="rk45", auto_reset=False, record_flags=True, record_nfev=True, timestep=dt)
+        env.set_state(s, m0=torch.as_tensor(m0))
+        env.step(torch.as_tensor(a))
+        post = env.get_state().cpu().numpy().astype(np.float64)
+        flags = env.flags.cpu().numpy()
+        nfev = env.nfev.cpu().numpy().astype(int)
+        errs, same_nfev, bad_status = [], 0, 0
+        for i in range(n):
+            y, status, nf = onp.sim_step_adaptive(s[i].astype(np.float64), onp.denormalize_action(a[i]), float(m0[i]), dt)
+            bad_status += int((flags[i] & 1) != (status == 1))
+            errs.append(float(np.max(np.abs(post[i] - y) / np.maximum(np.abs(y), P2.normalizer))))
+            same_nfev += int(nf == nfev[i])
+        errs = np.array(errs)
+        print(f"[rk45 fuzz dt={dt}] worst {errs.max():.2e}, {100 * (errs < 1e-5).mean():.1f}% within 1e-5, status mismatches "
+              f"{bad_status}, nfev equal on {100 * same_nfev / n:.1f}%, events {int((flags & 1).sum())}")
+        assert bad_status == 0
+        assert errs.max() < 1e-4 and (errs < 1e-5).mean() >= 0.99
+        assert same_nfev >= 0.9 * n
