@@ -37,6 +37,15 @@
 
 extern "C" void r6_internal_set_error(const char* what);
 
+#ifndef R6P_BLOCK64
+#define R6P_BLOCK64 512
+#define R6P_WAVES64 4
+#endif
+#ifndef R6P_BLOCK128
+#define R6P_BLOCK128 768
+#define R6P_WAVES128 3
+#endif
+
 namespace r6p {
 
 // Workgroup size per net shape: the LDS weight image is shared by the whole workgroup, so the wider net
@@ -45,7 +54,7 @@ namespace r6p {
 // two layers of accumulators, and what lets one wave's tanh run under another wave's MFMAs.
 template <int H1>
 struct Shape {
-    static constexpr int kBlock = (H1 > 64) ? 768 : 256;
+    static constexpr int kBlock = (H1 > 64) ? R6P_BLOCK128 : R6P_BLOCK64;
     static constexpr int kWaves = kBlock / 64;
 };
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -83,13 +92,13 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// tanh(x) = 1 - 2 / (exp(2x) + 1): two quarter-rate ops, absolute error ~1e-7 (saturates cleanly)
-__device__ __forceinline__ float tanh_fast(float x) {
-#ifdef R6P_NO_TANH   // timing experiment
-    return fminf(fmaxf(x, -1.0f), 1.0f);
-#endif
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // 2 / ln 2
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+// tanh(z) = 1 - 2 r,  r = 1 / (exp(2z) + 1).  The kernel only ever forms r (exp2, add, rcp: the two quarter-rate
+// ops are the VALU floor of this kernel; absolute error ~1e-7, saturates cleanly): the scale 2/ln2 of the
+// exponent is folded into the weights and bias of the layer that PRODUCES z, and the affine map 1 - 2 r into the
+// layer that CONSUMES it,  W a + b = (b + rowsum W) - 2 W r  -- both done once, when the weights are staged.
+constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
+__device__ __forceinline__ float half_sigmoid(float z_scaled) {
+    return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z_scaled) + 1.0f);
 }
 
 // LDS image, H1/H2 = hidden widths (multiples of 32), NET in {0 = pi, 1 = vf}.  Half-precision part
@@ -113,7 +122,7 @@ struct Image {
 };
 
 template <int H1, int H2, int OD>
-__global__ __launch_bounds__(Shape<H1>::kBlock, 3) void policy_act_kernel(const R6PolicyNet net, const float* __restrict__ obs, const int64_t n,
+__global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_WAVES64) void policy_act_kernel(const R6PolicyNet net, const float* __restrict__ obs, const int64_t n,
                                                             float* __restrict__ action, float* __restrict__ raw_action,
                                                             float* __restrict__ value, float* __restrict__ logp,
                                                             const uint64_t seed, const uint64_t step_index,
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, 3) void policy_act_kernel(const 
         const int m = mb * 32 + (l & 31);
         const float* w = nt ? net.vf_w1 : net.pi_w1;
         const float* b = nt ? net.vf_b1 : net.pi_b1;
-        put_split(Im::oW1h, Im::oW1l, e, (k < OD) ? w[m * OD + k] : ((k == kBiasK) ? b[m] : 0.0f));
+        put_split(Im::oW1h, Im::oW1l, e, kExpScale * ((k < OD) ? w[m * OD + k] : ((k == kBiasK) ? b[m] : 0.0f)));
     }
 #pragma unroll 8
     for (int e = tid; e < Im::kW2; e += kBlock) {
@@ -151,23 +160,33 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, 3) void policy_act_kernel(const 
         const int k = 32 * b + rowmap(8 * sstep + j, l >> 5);
         const int m = mb * 32 + (l & 31);
         const float* w = nt ? net.vf_w2 : net.pi_w2;
-        put_split(Im::oW2h, Im::oW2l, e, w[m * H1 + k]);
+        put_split(Im::oW2h, Im::oW2l, e, -2.0f * kExpScale * w[m * H1 + k]);
     }
     for (int e = tid; e < Im::kB2; e += kBlock) {
         const int r = e & 15, hh = (e >> 4) & 1, rest = e >> 5;
         const int mb = rest % (H2 / 32), nt = rest / (H2 / 32);
         const float* b = nt ? net.vf_b2 : net.pi_b2;
-        lds[Im::oB2 + e] = b[mb * 32 + rowmap(r, hh)];
+        const float* w = nt ? net.vf_w2 : net.pi_w2;
+        const int m = mb * 32 + rowmap(r, hh);
+        float rs = 0.0f;
+        for (int k = 0; k < H1; ++k) rs += w[m * H1 + k];
+        lds[Im::oB2 + e] = kExpScale * (b[m] + rs);
     }
     for (int e = tid; e < Im::kW3; e += kBlock) {
         const int o = e & 3, r = (e >> 2) & 15, rest = e >> 6;
         const int b = rest % (H2 / 32), hh = rest / (H2 / 32);
         const int k = 32 * b + rowmap(r, hh);
-        lds[Im::oW3 + e] = (o < 3) ? net.pi_w3[o * H2 + k] : net.vf_w3[k];
+        lds[Im::oW3 + e] = -2.0f * ((o < 3) ? net.pi_w3[o * H2 + k] : net.vf_w3[k]);
     }
     __syncthreads();
 
-    const float b3_0 = net.pi_b3[0], b3_1 = net.pi_b3[1], b3_2 = net.pi_b3[2], b3_v = net.vf_b3[0];
+    float b3_0 = net.pi_b3[0], b3_1 = net.pi_b3[1], b3_2 = net.pi_b3[2], b3_v = net.vf_b3[0];
+    for (int k = 0; k < H2; ++k) {   // + rowsum W3 (the 1 of 1 - 2 r); uniform scalar loads
+        b3_0 += net.pi_w3[k];
+        b3_1 += net.pi_w3[H2 + k];
+        b3_2 += net.pi_w3[2 * H2 + k];
+        b3_v += net.vf_w3[k];
+    }
     const float ls0 = net.log_std[0], ls1 = net.log_std[1], ls2 = net.log_std[2];
 
     const int64_t n_tiles = (n + 31) >> 5;
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, 3) void policy_act_kernel(const 
 #pragma unroll
             for (int mb = 0; mb < H1 / 32; ++mb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a1[mb][r] = tanh_fast(a1[mb][r]);
+                for (int r = 0; r < 16; ++r) a1[mb][r] = half_sigmoid(a1[mb][r]);
             }
 
             // ---- layer 2: accumulators start at the bias; registers 8s..8s+7 of a1[b] are K-step (b, s) ------------
@@ -248,20 +267,30 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, 3) void policy_act_kernel(const 
                 asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
             }
 
-            // ---- tanh + last layer on the VALU: this half's 16 rows per block ------------------------------
+            // ---- r of layer 2, then the last layer on the VALU: this half's 16 rows per block (one uniform
+            //      branch per network, not per value) --------------------------------------------------------
 #pragma unroll
             for (int mb = 0; mb < H2 / 32; ++mb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = tanh_fast(a2[mb][r]);
-                    const f32x4 w3 = *(const f32x4*)&lds[Im::oW3 + ((h * (H2 / 32) + mb) * 16 + r) * 4];
-                    if (nt == 0) {
-                        part[0] = fmaf(w3[0], v, part[0]);
-                        part[1] = fmaf(w3[1], v, part[1]);
-                        part[2] = fmaf(w3[2], v, part[2]);
-                    } else {
-                        part[3] = fmaf(w3[3], v, part[3]);
+                for (int r = 0; r < 16; ++r) a2[mb][r] = half_sigmoid(a2[mb][r]);
+            }
+            if (nt == 0) {
+#pragma unroll
+                for (int mb = 0; mb < H2 / 32; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x4 w3 = *(const f32x4*)&lds[Im::oW3 + ((h * (H2 / 32) + mb) * 16 + r) * 4];
+                        part[0] = fmaf(w3[0], a2[mb][r], part[0]);
+                        part[1] = fmaf(w3[1], a2[mb][r], part[1]);
+                        part[2] = fmaf(w3[2], a2[mb][r], part[2]);
                     }
+                }
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < H2 / 32; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        part[3] = fmaf(lds[Im::oW3 + ((h * (H2 / 32) + mb) * 16 + r) * 4 + 3], a2[mb][r], part[3]);
                 }
             }
         }
