@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's montecarlo_script.py: fly N episodes with a trained policy (deterministic actions)
+and report mean / standard deviation of the terminal-state errors it writes to results_montecarlo.csv
+(montecarlo_script.py:33-51: final position / velocity error, attitude error, angular-velocity error, terminal
+mass).  The reference runs 30 episodes of one env through SB3's evaluate_policy; here N envs fly at once, the policy
+forward and the env step are one HIP launch each.
+
+    python examples/montecarlo.py --checkpoint /path/to/best_model_2bo71j9m.zip --episodes 100000
+
+``--checkpoint`` is a stable-baselines3 PPO zip (only its tensors are read, torch.load(weights_only=True));
+without it a freshly initialised policy is flown (a smoke run).
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rl_rocket_6dof_amd import BatchedRocket6DOF, load_config
+from rl_rocket_6dof_amd.policy import FusedActorCritic, load_sb3_policy
+from rl_rocket_6dof_amd.ppo import ActorCritic
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--episodes", type=int, default=100_000)
+    ap.add_argument("--config", default=None)
+    ap.add_argument("--integrator", default="rk4", choices=["rk4", "rk45", "euler"])
+    ap.add_argument("--max-steps", type=int, default=1500)       # main_6DOF.py:31 max_time / timestep
+    args = ap.parse_args()
+
+    _, env_config = load_config(args.config)
+    n = args.episodes
+    # the full 14-dim observation is kept in the env (the terminal mass is one of the reported columns);
+    # the policy sees the RemoveMassFromObs view (wrappers.py:119-126) when it was trained on 13 inputs
+    policy = load_sb3_policy(args.checkpoint) if args.checkpoint else ActorCritic(13, 3, (128, 64), shared_trunk=True).cuda()
+    fused = FusedActorCritic(policy)
+    env = BatchedRocket6DOF(n, env_config, integrator=args.integrator, auto_reset=True, seed=env_config.get("seed", 42))
+    obs = env.reset()
+    first = torch.ones(n, dtype=torch.bool, device=env.device)           # still flying its first episode
+    cols = {}
+    for _ in range(args.max_steps):
+        pol_in = obs[:, : fused.obs_dim].contiguous()
+        obs, _, done, _ = env.step(fused(pol_in, deterministic=True)[0])
+        if bool(done.any()):
+            te = env.terminal_errors()
+            keep = first[te["env_index"]]
+            for k, v in te.items():
+                if k != "env_index":
+                    cols.setdefault(k, []).append(v[keep])
+            first &= ~done
+        if not bool(first.any()):
+            break
+    print(f"{n - int(first.sum())} of {n} episodes finished")
+    for k, v in cols.items():
+        v = torch.cat(v)
+        print(f"The {k} has mean:{float(v.mean()):.4f} and standard deviation: {float(v.std()):.4f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -175,7 +175,10 @@ int r6_rhs(const R6Params *params, const float *y, const float *epconst, const f
 typedef struct R6PolicyNet {
     int32_t obs_dim;            /* 13 | 14 (= R6Params.obs_dim) */
     int32_t hidden1, hidden2;   /* (64, 64) or (128, 64) */
-    int32_t reserved0;
+    int32_t shared;             /* 0: separate policy / value MLPs (SB3 default, net_arch=[dict(pi=.., vf=..)]);
+                                   1: ONE trunk feeding both heads -- what SB3 1.6 builds for a plain list such as
+                                   the reference's net_arch=[128, 64] (main_6DOF.py:113; its checkpoints hold
+                                   mlp_extractor.shared_net.*): pi_w1/b1/w2/b2 are the trunk, vf_w1..vf_b2 unused */
     const float *pi_w1, *pi_b1; /* [hidden1][obs_dim], [hidden1] */
     const float *pi_w2, *pi_b2; /* [hidden2][hidden1], [hidden2] */
     const float *pi_w3, *pi_b3; /* [3][hidden2], [3]   (action mean) */

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
         const int mb = rest % (H1 / 32), nt = rest / (H1 / 32);
         const int k = 8 * (l >> 5) + j;
         const int m = mb * 32 + (l & 31);
+        if (nt && net.shared) continue;   // one trunk: the second network's image is never read
         const float* w = nt ? net.vf_w1 : net.pi_w1;
         const float* b = nt ? net.vf_b1 : net.pi_b1;
         put_split(Im::oW1h, Im::oW1l, e, kExpScale * ((k < OD) ? w[m * OD + k] : ((k == kBiasK) ? b[m] : 0.0f)));
@@ -159,12 +160,14 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
         const int b = rest % (H1 / 32), mb = (rest / (H1 / 32)) % (H2 / 32), nt = rest / ((H1 / 32) * (H2 / 32));
         const int k = 32 * b + rowmap(8 * sstep + j, l >> 5);
         const int m = mb * 32 + (l & 31);
+        if (nt && net.shared) continue;
         const float* w = nt ? net.vf_w2 : net.pi_w2;
         put_split(Im::oW2h, Im::oW2l, e, -2.0f * kExpScale * w[m * H1 + k]);
     }
     for (int e = tid; e < Im::kB2; e += kBlock) {
         const int r = e & 15, hh = (e >> 4) & 1, rest = e >> 5;
         const int mb = rest % (H2 / 32), nt = rest / (H2 / 32);
+        if (nt && net.shared) continue;
         const float* b = nt ? net.vf_b2 : net.pi_b2;
         const float* w = nt ? net.vf_w2 : net.pi_w2;
         const int m = mb * 32 + rowmap(r, hh);
@@ -220,8 +223,9 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // this lane half's share of (mean0, mean1, mean2, value)
         // one network at a time (rolled): the two share nothing but x[], and unrolled the scheduler
         // interleaves them and triples the live registers
+        const int n_nets = net.shared ? 1 : 2;   // one trunk feeds both heads, or one MLP per head
 #pragma unroll 1
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < n_nets; ++nt) {
             // ---- layer 1: one K = 16 step per 32-feature block, B = the split obs row ---------------------------
             f32x16 a1[H1 / 32];
 #pragma unroll
@@ -274,7 +278,19 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a2[mb][r] = half_sigmoid(a2[mb][r]);
             }
-            if (nt == 0) {
+            if (net.shared) {          // both heads read the one trunk
+#pragma unroll
+                for (int mb = 0; mb < H2 / 32; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x4 w3 = *(const f32x4*)&lds[Im::oW3 + ((h * (H2 / 32) + mb) * 16 + r) * 4];
+                        part[0] = fmaf(w3[0], a2[mb][r], part[0]);
+                        part[1] = fmaf(w3[1], a2[mb][r], part[1]);
+                        part[2] = fmaf(w3[2], a2[mb][r], part[2]);
+                        part[3] = fmaf(w3[3], a2[mb][r], part[3]);
+                    }
+                }
+            } else if (nt == 0) {
 #pragma unroll
                 for (int mb = 0; mb < H2 / 32; ++mb) {
 #pragma unroll
@@ -383,9 +399,12 @@ extern "C" int r6_policy_act(const R6PolicyNet* net, const float* obs, int64_t n
     }
     if (n == 0) return 0;
     const R6PolicyNet& p = *net;
-    if (!p.pi_w1 || !p.pi_b1 || !p.pi_w2 || !p.pi_b2 || !p.pi_w3 || !p.pi_b3 || !p.vf_w1 || !p.vf_b1 || !p.vf_w2 || !p.vf_b2 ||
-        !p.vf_w3 || !p.vf_b3 || !p.log_std) {
-        r6_internal_set_error("r6_policy_act: every weight pointer of R6PolicyNet is required");
+    if (!p.pi_w1 || !p.pi_b1 || !p.pi_w2 || !p.pi_b2 || !p.pi_w3 || !p.pi_b3 || !p.vf_w3 || !p.vf_b3 || !p.log_std) {
+        r6_internal_set_error("r6_policy_act: trunk / head weight pointers of R6PolicyNet are required");
+        return R6_E_BADARG;
+    }
+    if (!p.shared && (!p.vf_w1 || !p.vf_b1 || !p.vf_w2 || !p.vf_b2)) {
+        r6_internal_set_error("r6_policy_act: a net with separate MLPs (shared == 0) needs vf_w1, vf_b1, vf_w2, vf_b2");
         return R6_E_BADARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -70,7 +70,7 @@ class R6Buffers(C.Structure):
 class R6PolicyNet(C.Structure):
     """include/r6dof.h ``R6PolicyNet``: device pointers to fp32 weights in torch.nn.Linear layout."""
     _fields_ = [
-        ("obs_dim", C.c_int32), ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("reserved0", C.c_int32),
+        ("obs_dim", C.c_int32), ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("shared", C.c_int32),
         ("pi_w1", C.c_void_p), ("pi_b1", C.c_void_p), ("pi_w2", C.c_void_p), ("pi_b2", C.c_void_p),
         ("pi_w3", C.c_void_p), ("pi_b3", C.c_void_p),
         ("vf_w1", C.c_void_p), ("vf_b1", C.c_void_p), ("vf_w2", C.c_void_p), ("vf_b2", C.c_void_p),

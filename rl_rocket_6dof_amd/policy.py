@@ -33,6 +33,7 @@ class FusedActorCritic:
             raise ValueError("the fused forward supports two hidden layers per network")
         self.obs_dim = pi[0].in_features
         arch = (pi[0].out_features, pi[1].out_features)
+        self.shared = pi[0] is vf[0] and pi[1] is vf[1]        # SB3 1.6 plain-list net_arch: one trunk, two heads
         if arch not in SUPPORTED_ARCHS or (vf[0].out_features, vf[1].out_features) != arch or self.obs_dim not in (13, 14):
             raise ValueError(f"supported: obs_dim 13|14, hidden {SUPPORTED_ARCHS}; got obs_dim {self.obs_dim}, hidden {arch}")
         if pi[2].out_features != 3 or vf[2].out_features != 1:
@@ -50,7 +51,7 @@ class FusedActorCritic:
     def _net(self) -> R6PolicyNet:
         # rebuilt per call: optimisers update parameters in place, but .data_ptr() is what the launch needs
         net = R6PolicyNet()
-        net.obs_dim, net.hidden1, net.hidden2 = self.obs_dim, self.arch[0], self.arch[1]
+        net.obs_dim, net.hidden1, net.hidden2, net.shared = self.obs_dim, self.arch[0], self.arch[1], int(self.shared)
         names = ("pi_w1", "pi_b1", "pi_w2", "pi_b2", "pi_w3", "pi_b3", "vf_w1", "vf_b1", "vf_w2", "vf_b2", "vf_w3", "vf_b3", "log_std")
         for name, t in zip(names, self._params):
             setattr(net, name, t.data_ptr())
@@ -80,3 +81,43 @@ class FusedActorCritic:
         return act, raw, val, logp
 
     __call__ = forward
+
+
+def load_sb3_policy(path: str, device="cuda"):
+    """Builds a ``ppo.ActorCritic`` from a stable-baselines3 (1.x) PPO checkpoint ``*.zip`` -- the format of
+    the reference's ``best_model_*.zip`` (``PPO.load`` in montecarlo_script.py / main_6DOF.py) -- without SB3.
+
+    Only the JSON ``data`` entry and the tensors of ``policy.pth`` are read; the tensors are loaded with
+    ``torch.load(..., weights_only=True)``, so no pickled code of the checkpoint is ever executed.
+    Both SB3 topologies are recognised: ``mlp_extractor.policy_net`` / ``value_net`` (separate MLPs) and
+    ``mlp_extractor.shared_net`` (plain-list ``net_arch``, one trunk)."""
+    import io
+    import zipfile
+
+    from .ppo import ActorCritic
+
+    with zipfile.ZipFile(path) as z:
+        sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+    return policy_from_sb3_state_dict(sd, device=device)
+
+
+def policy_from_sb3_state_dict(sd, device="cuda"):
+    """``ActorCritic`` from the tensors of an SB3 ``ActorCriticPolicy.state_dict()`` (two tanh hidden layers)."""
+    from .ppo import ActorCritic
+
+    shared = any(k.startswith("mlp_extractor.shared_net.") for k in sd)
+    pre = "mlp_extractor.shared_net." if shared else "mlp_extractor.policy_net."
+    w1, w2 = sd[pre + "0.weight"], sd[pre + "2.weight"]
+    pol = ActorCritic(w1.shape[1], sd["action_net.weight"].shape[0], (w1.shape[0], w2.shape[0]), shared_trunk=shared)
+    lin = lambda seq: [m for m in seq if isinstance(m, torch.nn.Linear)]
+    pi, vf = lin(pol.pi), lin(pol.vf)
+    with torch.no_grad():
+        for m, key in ((pi[0], pre + "0"), (pi[1], pre + "2"), (pi[2], "action_net"), (vf[2], "value_net")):
+            m.weight.copy_(sd[key + ".weight"])
+            m.bias.copy_(sd[key + ".bias"])
+        if not shared:
+            for m, key in ((vf[0], "mlp_extractor.value_net.0"), (vf[1], "mlp_extractor.value_net.2")):
+                m.weight.copy_(sd[key + ".weight"])
+                m.bias.copy_(sd[key + ".bias"])
+        pol.log_std.copy_(sd["log_std"])
+    return pol.to(device)

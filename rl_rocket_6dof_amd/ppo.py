@@ -48,6 +48,7 @@ class PPOConfig:
     max_grad_norm: float = 0.5
     normalize_advantage: bool = True
     net_arch: Sequence[int] = (64, 64)   # SB3 MlpPolicy default; the reference's training run used [128, 64]
+    shared_trunk: bool = False           # True = SB3 1.6 semantics of a plain-list net_arch (one trunk, two heads)
     log_std_init: float = 0.0
     seed: int = 42
     graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
@@ -105,12 +106,29 @@ def _mlp(sizes, out_dim, out_gain):
 
 
 class ActorCritic(nn.Module):
-    """SB3 ``ActorCriticPolicy`` with a diagonal Gaussian action distribution."""
+    """SB3 1.6 ``ActorCriticPolicy`` with a diagonal Gaussian action distribution.
 
-    def __init__(self, obs_dim: int, act_dim: int, net_arch=(64, 64), log_std_init: float = 0.0):
+    ``shared_trunk=False``: separate tanh MLPs for policy and value -- SB3's default ``net_arch`` and the
+    ``[dict(pi=[..], vf=[..])]`` form.  ``shared_trunk=True``: ONE trunk feeding both heads -- what SB3 1.6
+    builds for a plain list, i.e. for the reference's ``policy_kwargs={'net_arch': [128, 64]}``
+    (main_6DOF.py:113; its checkpoints hold ``mlp_extractor.shared_net.*``).  Either way ``self.pi`` /
+    ``self.vf`` are the full obs -> mean / obs -> value stacks (sharing the trunk's modules when shared)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, net_arch=(64, 64), log_std_init: float = 0.0, shared_trunk: bool = False):
         super().__init__()
-        self.pi = _mlp([obs_dim, *net_arch], act_dim, 0.01)
-        self.vf = _mlp([obs_dim, *net_arch], 1, 1.0)
+        self.shared_trunk = bool(shared_trunk)
+        if self.shared_trunk:
+            trunk = list(_mlp([obs_dim, *net_arch[:-1]], net_arch[-1], math.sqrt(2))) + [nn.Tanh()]
+            pi_head, vf_head = TallLinear(net_arch[-1], act_dim), TallLinear(net_arch[-1], 1)
+            nn.init.orthogonal_(pi_head.weight, gain=0.01)
+            nn.init.orthogonal_(vf_head.weight, gain=1.0)
+            nn.init.zeros_(pi_head.bias)
+            nn.init.zeros_(vf_head.bias)
+            self.pi = nn.Sequential(*trunk, pi_head)
+            self.vf = nn.Sequential(*trunk, vf_head)      # same trunk modules: parameters are shared
+        else:
+            self.pi = _mlp([obs_dim, *net_arch], act_dim, 0.01)
+            self.vf = _mlp([obs_dim, *net_arch], 1, 1.0)
         self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
 
     def value(self, obs):
@@ -158,7 +176,7 @@ class PPO:
         self.device = env.device
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         torch.manual_seed(cfg.seed)          # identical initial weights on every rank
-        self.policy = (policy or ActorCritic(env.obs_dim, 3, cfg.net_arch, cfg.log_std_init)).to(self.device)
+        self.policy = (policy or ActorCritic(env.obs_dim, 3, cfg.net_arch, cfg.log_std_init, cfg.shared_trunk)).to(self.device)
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                     capturable=(self.device.type == "cuda" and cfg.graph_update))
         self._graph, self._graph_key, self._eager_steps = None, None, 0

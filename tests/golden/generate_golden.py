@@ -19,6 +19,12 @@ What each file pins (reference file:line):
                    integrator; this is the parity oracle for BASELINE configs 2-3)
   g7_wrappers      RewardAnnealing / VerticalAttitudeReward (my_environment/wrappers/wrappers.py:39-61,
                    :128-155) around the reference env   (python generate_golden.py --only g7)
+  g8_closed_loop   whole landing episodes of the reference env (RemoveMassFromObs view, wrappers.py:119-126)
+                   flown by the reference's own trained policies (best_model_*.zip, the checkpoints
+                   montecarlo_script.py / main_6DOF.py load with PPO.load), deterministic actions clipped to
+                   the Box like SB3's predict.  The checkpoint tensors are read with
+                   torch.load(weights_only=True) -- no pickled code is executed -- and stored in the fixture
+                   (they are the reference's data files, 10 k floats each)   (--only g8)
 """
 from __future__ import annotations
 
@@ -189,9 +195,76 @@ def gen_g7():
     np.savez_compressed(os.path.join(HERE, "g7_wrappers.npz"), config=np.array(json.dumps(cfg)), meta=_meta(), **out)
 
 
+def _sb3_forward(sd, obs13):
+    """Deterministic SB3 ActorCriticPolicy forward (mean action) from the checkpoint tensors, float32 torch."""
+    import torch
+
+    x = torch.as_tensor(obs13, dtype=torch.float32)
+    pre = "mlp_extractor.shared_net." if any(k.startswith("mlp_extractor.shared_net.") for k in sd) else "mlp_extractor.policy_net."
+    h = torch.tanh(torch.nn.functional.linear(x, sd[pre + "0.weight"], sd[pre + "0.bias"]))
+    h = torch.tanh(torch.nn.functional.linear(h, sd[pre + "2.weight"], sd[pre + "2.bias"]))
+    return torch.nn.functional.linear(h, sd["action_net.weight"], sd["action_net.bias"]).numpy()
+
+
+def gen_g8():
+    import io
+    import zipfile
+
+    import torch
+
+    from _ref_loader import REF_ROOT
+
+    Sim, Env, cfg = load_reference()
+    out = {}
+    for name in ("best_model_2bo71j9m", "best_model_2i3ipkag"):
+        with zipfile.ZipFile(os.path.join(REF_ROOT, name + ".zip")) as z:
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)   # tensors only
+        tag = name.split("_")[-1]
+        for k, v in sd.items():
+            out[f"{tag}_w_{k}"] = v.numpy().astype(np.float32)
+        env = Env(**cfg)
+        env.seed(1234)
+        ics, n_steps, terminal, returns, landed, traj_obs, traj_act = [], [], [], [], [], [], []
+        for ep in range(12):
+            obs = env.reset()
+            ics.append(np.array(env.SIM.state, dtype=np.float64))
+            ret, k, o_hist, a_hist = 0.0, 0, [], []
+            for k in range(1500):
+                a = np.clip(_sb3_forward(sd, obs[0:13]), -1.0, 1.0).astype(np.float32)     # SB3 predict clips to the Box
+                if k % 25 == 0:
+                    o_hist.append(np.asarray(obs[0:13], dtype=np.float32))
+                    a_hist.append(a)
+                obs, rew, done, info = env.step(a)
+                ret += float(rew)
+                if done:
+                    break
+            n_steps.append(k + 1)
+            terminal.append(np.array(env.SIM.state, dtype=np.float64))
+            returns.append(ret)
+            landed.append(float(info["rewards_dict"]["goal_conditions"]) != 0.0)
+            pad = 20 - len(o_hist)
+            traj_obs.append(np.array(o_hist + [np.zeros(13, np.float32)] * pad)[:20])
+            traj_act.append(np.array(a_hist + [np.zeros(3, np.float32)] * pad)[:20])
+        out[f"{tag}_ic"] = np.array(ics)
+        out[f"{tag}_n_steps"] = np.array(n_steps)
+        out[f"{tag}_terminal"] = np.array(terminal)
+        out[f"{tag}_return"] = np.array(returns)
+        out[f"{tag}_landed"] = np.array(landed)
+        out[f"{tag}_obs_every25"] = np.array(traj_obs)
+        out[f"{tag}_act_every25"] = np.array(traj_act)
+        t = np.array(terminal)
+        print("G8", name, "steps", n_steps, "landed", int(np.sum(landed)), "of", len(landed),
+              "| |r_T| mean %.2f m, |v_T| mean %.2f m/s, return mean %.1f" % (np.linalg.norm(t[:, 0:3], axis=1).mean(),
+                                                                            np.linalg.norm(t[:, 3:6], axis=1).mean(), np.mean(returns)))
+    np.savez_compressed(os.path.join(HERE, "g8_closed_loop.npz"), config=np.array(json.dumps(cfg)), meta=_meta(), **out)
+
+
 def main():
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g7":
         gen_g7()
+        return
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g8":
+        gen_g8()
         return
     Sim, Env, cfg = load_reference()
     sim_module = sys.modules["my_environment.utils.simulator"]

@@ -19,11 +19,11 @@ def torch_cuda():
     return torch
 
 
-def _policy(torch, obs_dim, arch, seed=0, scale=1.0):
+def _policy(torch, obs_dim, arch, seed=0, scale=1.0, shared=False):
     from rl_rocket_6dof_amd.ppo import ActorCritic
 
     torch.manual_seed(seed)
-    pol = ActorCritic(obs_dim, 3, arch).cuda()
+    pol = ActorCritic(obs_dim, 3, arch, shared_trunk=shared).cuda()
     with torch.no_grad():   # SB3's init keeps the action head at gain 0.01: scale the nets up to O(1) outputs
         for p in pol.parameters():
             if p.dim() == 2:
@@ -40,13 +40,14 @@ def _close(got, want, tol, what):
     return float(err.max())
 
 
+@pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("obs_dim,arch", [(14, (64, 64)), (13, (64, 64)), (14, (128, 64)), (13, (128, 64))])
 @pytest.mark.parametrize("n", [1, 31, 33, 1000, 70001])
-def test_deterministic_forward_matches_torch(torch_cuda, obs_dim, arch, n):
+def test_deterministic_forward_matches_torch(torch_cuda, obs_dim, arch, n, shared):
     torch = torch_cuda
     from rl_rocket_6dof_amd.policy import FusedActorCritic
 
-    pol = _policy(torch, obs_dim, arch, seed=n, scale=2.0)
+    pol = _policy(torch, obs_dim, arch, seed=n, scale=2.0, shared=shared)
     fused = FusedActorCritic(pol)
     obs = (torch.rand((n, obs_dim), device="cuda") * 2 - 1).contiguous()
     act, raw, val, logp = fused(obs, deterministic=True)
@@ -141,3 +142,64 @@ def test_weights_are_read_in_place_and_bad_nets_are_refused(torch_cuda):
         FusedActorCritic(ActorCritic(14, 3, (48, 48)).cuda())
     with pytest.raises(ValueError):
         fused(obs.double())
+
+
+@pytest.mark.parametrize("tag,shared", [("2bo71j9m", True), ("2i3ipkag", False)])
+@pytest.mark.parametrize("integ", ["rk4", "rk45"])
+def test_reference_checkpoints_fly_the_same_landings(torch_cuda, tag, shared, integ):
+    """End to end, closed loop: golden G8 holds 12 whole episodes of the REFERENCE env flown by the reference's own
+    trained policies (best_model_*.zip: one plain-list net_arch = shared trunk, one SB3-default separate MLPs;
+    deterministic, clipped like SB3's predict).  Here the same weights go through ``policy_from_sb3_state_dict``
+    and the fused HIP forward, the same initial conditions through the HIP env: ~300 steps of feedback later
+    the episodes must end on the same step, in the same place.  Closed loop, the 1e-7 per-step differences are
+    fed back through the policy (whose gain is large: a 1e-6 change of an observation moves an action by up to
+    1e-3), so the bounds are 2e-4 of the normaliser scale on the terminal state (measured 6e-6 / 1.2e-5, i.e.
+    1 cm after 300 steps) and 1e-2 on the observations / actions logged every 25 steps (measured 4e-4 / 3e-3)."""
+    torch = torch_cuda
+    from tests.conftest import load_golden
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.policy import FusedActorCritic, policy_from_sb3_state_dict
+
+    G = load_golden("g8_closed_loop.npz")
+    import json
+
+    cfg = json.loads(str(G["config"]))
+    sd = {k[len(tag) + 3:]: torch.as_tensor(G[k]) for k in G.files if k.startswith(tag + "_w_")}
+    pol = policy_from_sb3_state_dict(sd)
+    assert pol.shared_trunk == shared
+    fused = FusedActorCritic(pol)
+    assert fused.shared == shared
+    ic = G[f"{tag}_ic"]
+    n = len(ic)
+    env = BatchedRocket6DOF(n, cfg, integrator=integ, remove_mass=True, auto_reset=False)
+    obs = env.set_state(torch.as_tensor(ic, dtype=torch.float32))
+    n_steps = np.zeros(n, dtype=int)
+    terminal = np.zeros((n, 14))
+    alive = np.ones(n, dtype=bool)
+    worst_track = 0.0
+    for k in range(1500):
+        act, raw, _, _ = fused(obs.contiguous(), deterministic=True)
+        if k % 25 == 0 and k // 25 < 20:
+            j = k // 25
+            o_ref, a_ref = G[f"{tag}_obs_every25"][:, j], G[f"{tag}_act_every25"][:, j]
+            live = alive & (G[f"{tag}_n_steps"] > k)
+            if live.any():
+                worst_track = max(worst_track, float(np.abs(obs.cpu().numpy()[live] - o_ref[live]).max()),
+                                  float(np.abs(act.cpu().numpy()[live] - a_ref[live]).max()))
+        obs, rew, done, _ = env.step(act)
+        d = done.cpu().numpy().astype(bool) & alive
+        if d.any():
+            st = env.get_state().cpu().numpy()
+            n_steps[d] = k + 1
+            terminal[d] = st[d]
+            alive &= ~d
+        if not alive.any():
+            break
+    assert not alive.any()
+    np.testing.assert_array_equal(n_steps, G[f"{tag}_n_steps"])
+    scale = np.array([2400, 2400, 2400, 615, 615, 615, 1.1, 1.1, 1.1, 1.1, 5.2, 5.2, 5.2, 42000.0])
+    err = np.abs(terminal - G[f"{tag}_terminal"]) / scale
+    print(f"[G8 {tag} {integ}] episodes end on the reference's step; terminal state within {err.max():.2e} of the normaliser scale "
+          f"(|dr| max {np.abs(terminal[:, :3] - G[f'{tag}_terminal'][:, :3]).max():.3f} m), obs/actions en route within {worst_track:.2e}")
+    assert err.max() < 2e-4 and worst_track < 1e-2

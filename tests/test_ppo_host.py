@@ -158,3 +158,55 @@ def test_two_rank_gradient_averaging_keeps_replicas_identical():
         assert p.exitcode == 0
     np.testing.assert_array_equal(res[0][1], res[1][1])     # same init + averaged grads => same weights
     assert res[0][2] == 3 * 20 * 64 * 2                     # timesteps count the whole job
+
+
+def test_sb3_checkpoint_tensors_map_onto_both_topologies():
+    """policy.policy_from_sb3_state_dict on the reference's own checkpoints (tensors in golden G8): the plain-list
+    net_arch=[128, 64] checkpoint is ONE shared trunk (10 311 parameters), the default one two separate MLPs; the
+    rebuilt modules reproduce the deterministic actions the reference env saw (logged every 25 steps)."""
+    import numpy as np
+    import torch
+
+    from rl_rocket_6dof_amd.policy import policy_from_sb3_state_dict
+    from tests.conftest import load_golden
+
+    G = load_golden("g8_closed_loop.npz")
+    for tag, shared, n_par in (("2bo71j9m", True, 10311), ("2i3ipkag", False, 10375)):
+        sd = {k[len(tag) + 3:]: torch.as_tensor(G[k]) for k in G.files if k.startswith(tag + "_w_")}
+        pol = policy_from_sb3_state_dict(sd, device="cpu")
+        assert pol.shared_trunk == shared
+        assert sum(p.numel() for p in pol.parameters()) == n_par
+        obs, act = G[f"{tag}_obs_every25"], G[f"{tag}_act_every25"]
+        live = np.abs(obs).sum(axis=2) > 0
+        with torch.no_grad():
+            mean = pol.pi(torch.as_tensor(obs[live])).clamp(-1, 1).numpy()
+        np.testing.assert_allclose(mean, act[live], rtol=0, atol=2e-6)
+
+
+def test_load_sb3_policy_reads_a_checkpoint_zip_tensor_only(tmp_path):
+    """policy.load_sb3_policy on a zip laid out like SB3's ``model.save`` (policy.pth inside), built here from the
+    reference checkpoint tensors of golden G8; the loader uses torch.load(weights_only=True)."""
+    import io
+    import zipfile
+
+    import numpy as np
+    import torch
+
+    from rl_rocket_6dof_amd.policy import load_sb3_policy
+    from tests.conftest import load_golden
+
+    G = load_golden("g8_closed_loop.npz")
+    tag = "2bo71j9m"
+    sd = {k[len(tag) + 3:]: torch.as_tensor(G[k]) for k in G.files if k.startswith(tag + "_w_")}
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    path = tmp_path / "best_model.zip"
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("policy.pth", buf.getvalue())
+        z.writestr("data", "{}")
+    pol = load_sb3_policy(str(path), device="cpu")
+    assert pol.shared_trunk
+    obs = G[f"{tag}_obs_every25"][:, 0]
+    with torch.no_grad():
+        got = pol.pi(torch.as_tensor(obs)).clamp(-1, 1).numpy()
+    np.testing.assert_allclose(got, G[f"{tag}_act_every25"][:, 0], rtol=0, atol=2e-6)
