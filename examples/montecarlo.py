@@ -18,13 +18,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from rl_rocket_6dof_amd import BatchedRocket6DOF, load_config
-from rl_rocket_6dof_amd.policy import FusedActorCritic, load_sb3_policy
+from rl_rocket_6dof_amd.policy import FusedActorCritic, load_policy, load_sb3_policy
 from rl_rocket_6dof_amd.ppo import ActorCritic
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--checkpoint", default=None)
+    ap.add_argument("--checkpoint", default=None, help="stable-baselines3 PPO zip (the reference's best_model_*.zip)")
+    ap.add_argument("--policy", default=None, help="state_dict written by examples/train_ppo.py --save")
     ap.add_argument("--episodes", type=int, default=100_000)
     ap.add_argument("--config", default=None)
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "rk45", "euler"])
@@ -35,9 +36,15 @@ def main():
     n = args.episodes
     # the full 14-dim observation is kept in the env (the terminal mass is one of the reported columns);
     # the policy sees the RemoveMassFromObs view (wrappers.py:119-126) when it was trained on 13 inputs
-    policy = load_sb3_policy(args.checkpoint) if args.checkpoint else ActorCritic(13, 3, (128, 64), shared_trunk=True).cuda()
+    if args.checkpoint:
+        policy = load_sb3_policy(args.checkpoint)
+    elif args.policy:
+        policy = load_policy(args.policy)
+    else:
+        policy = ActorCritic(13, 3, (128, 64), shared_trunk=True).cuda()
     fused = FusedActorCritic(policy)
-    env = BatchedRocket6DOF(n, env_config, integrator=args.integrator, auto_reset=True, seed=env_config.get("seed", 42))
+    env = BatchedRocket6DOF(n, env_config, integrator=args.integrator, auto_reset=True, track_episodes=True,
+                            seed=env_config.get("seed", 42))
     obs = env.reset()
     first = torch.ones(n, dtype=torch.bool, device=env.device)           # still flying its first episode
     cols = {}
@@ -54,6 +61,10 @@ def main():
         if not bool(first.any()):
             break
     print(f"{n - int(first.sum())} of {n} episodes finished")
+    stats = env.episode_stats() if env.stats is not None else None
+    if stats and stats["episodes"] > 0:
+        print(f"landed (all conditions of rocket_env.py:382-390): {100 * stats['landed'] / stats['episodes']:.2f} % of "
+              f"{int(stats['episodes'])} finished episodes; ground contact {100 * stats['ground'] / stats['episodes']:.1f} %")
     for k, v in cols.items():
         v = torch.cat(v)
         print(f"The {k} has mean:{float(v.mean()):.4f} and standard deviation: {float(v.std()):.4f}")

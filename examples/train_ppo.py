@@ -29,7 +29,13 @@ def main():
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--net-arch", default="128,64", help="main_6DOF.py:113 uses [128, 64]; SB3 default is 64,64")
+    ap.add_argument("--separate", action="store_true",
+                    help="two separate MLPs instead of SB3 1.6's meaning of a plain-list net_arch (one shared trunk, "
+                         "which is what the reference's net_arch=[128, 64] builds)")
     ap.add_argument("--config", default=None)
+    ap.add_argument("--save", default=None, help="write the policy state_dict here (torch.save) whenever the mean episode "
+                                                 "return of an iteration is the best so far (the reference keeps its "
+                                                 "best_model through SB3's EvalCallback, main_6DOF.py)")
     args = ap.parse_args()
 
     rank, world, local = r6dist.init_from_env()
@@ -39,11 +45,18 @@ def main():
     env = r6dist.make_sharded_env(args.envs, env_config, device=f"cuda:{local}", remove_mass=True,
                                   clip_reward=(-1, 100), max_episode_steps=max_steps, seed=env_config["seed"])
     cfg = PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, n_epochs=args.epochs, learning_rate=args.lr,
-                    net_arch=tuple(int(x) for x in args.net_arch.split(",")), seed=env_config["seed"])
+                    net_arch=tuple(int(x) for x in args.net_arch.split(",")), shared_trunk=not args.separate,
+                    seed=env_config["seed"])
     algo = PPO(env, cfg)
     t0 = time.time()
 
+    best = [-1e30]
+
     def log(info):
+        if rank == 0 and args.save and info.get("episodes", 0) > 100 and info["ep_rew_mean"] > best[0]:
+            best[0] = info["ep_rew_mean"]
+            torch.save(algo.policy.state_dict(), args.save)
+            info = dict(info, saved=True)
         if rank == 0:
             info = dict(info, wall_s=round(time.time() - t0, 1), sps=round(info["timesteps"] / (time.time() - t0)))
             print(json.dumps({k: (round(v, 5) if isinstance(v, float) else v) for k, v in info.items()}), flush=True)

@@ -121,3 +121,16 @@ def policy_from_sb3_state_dict(sd, device="cuda"):
                 m.bias.copy_(sd[key + ".bias"])
         pol.log_std.copy_(sd["log_std"])
     return pol.to(device)
+
+
+def load_policy(path: str, device="cuda"):
+    """``ActorCritic`` from a state_dict written by ``examples/train_ppo.py --save`` (tensor-only load); the
+    topology is read off the tensors (a shared trunk appears under both ``pi.*`` and ``vf.*`` with equal values)."""
+    from .ppo import ActorCritic
+
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    shared = all(k not in sd or torch.equal(sd[k], sd["pi" + k[2:]]) for k in ("vf.0.weight", "vf.0.bias", "vf.2.weight", "vf.2.bias"))
+    w1, w2 = sd["pi.0.weight"], sd["pi.2.weight"]
+    pol = ActorCritic(w1.shape[1], sd["pi.4.weight"].shape[0], (w1.shape[0], w2.shape[0]), shared_trunk=shared)
+    pol.load_state_dict(sd)
+    return pol.to(device)

@@ -131,6 +131,13 @@ class ActorCritic(nn.Module):
             self.vf = _mlp([obs_dim, *net_arch], 1, 1.0)
         self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
 
+    def _forward(self, obs):
+        """(action mean, value); the trunk is evaluated once when it is shared."""
+        if self.shared_trunk:
+            latent = self.pi[:-1](obs)
+            return self.pi[-1](latent), self.vf[-1](latent).squeeze(-1)
+        return self.pi(obs), self.vf(obs).squeeze(-1)
+
     def value(self, obs):
         return self.vf(obs).squeeze(-1)
 
@@ -140,18 +147,18 @@ class ActorCritic(nn.Module):
 
     @torch.no_grad()
     def act(self, obs, generator=None, deterministic=False):
-        mean = self.pi(obs)
+        mean, value = self._forward(obs)
         if deterministic:
             actions = mean
         else:
             noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
             actions = mean + noise * torch.exp(self.log_std)
-        return actions, self.value(obs), self._logp(mean, actions)
+        return actions, value, self._logp(mean, actions)
 
     def evaluate(self, obs, actions):
-        mean = self.pi(obs)
+        mean, value = self._forward(obs)
         entropy = (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std).sum().expand(obs.shape[0])
-        return self.value(obs), self._logp(mean, actions), entropy
+        return value, self._logp(mean, actions), entropy
 
 
 def compute_gae(rewards, values, dones, last_values, gamma: float, lam: float):

@@ -203,3 +203,36 @@ def test_reference_checkpoints_fly_the_same_landings(torch_cuda, tag, shared, in
     print(f"[G8 {tag} {integ}] episodes end on the reference's step; terminal state within {err.max():.2e} of the normaliser scale "
           f"(|dr| max {np.abs(terminal[:, :3] - G[f'{tag}_terminal'][:, :3]).max():.3f} m), obs/actions en route within {worst_track:.2e}")
     assert err.max() < 2e-4 and worst_track < 1e-2
+
+
+def test_shipped_policy_lands(torch_cuda):
+    """examples/policies/landing_policy_shared_128_64.pt was trained by examples/train_ppo.py on this stack
+    (2.1e9 env steps, 4.7 minutes on one MI355X; net_arch [128, 64] with SB3's shared trunk).  Flown
+    deterministically over 50 000 first episodes it must still meet all landing conditions of
+    rocket_env.py:382-390 in more than 80 % of them (86.5 % when it was saved) -- a whole-stack regression
+    test: env step, observation, fused policy forward, episode statistics."""
+    torch = torch_cuda
+    import os
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+    from rl_rocket_6dof_amd.policy import FusedActorCritic, load_policy
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pol = load_policy(os.path.join(root, "examples", "policies", "landing_policy_shared_128_64.pt"))
+    fused = FusedActorCritic(pol)
+    assert fused.shared and fused.arch == (128, 64) and fused.obs_dim == 13
+    n = 50_000
+    env = BatchedRocket6DOF(n, default_env_config(), auto_reset=True, track_episodes=True, seed=7)
+    obs = env.reset()
+    first = torch.ones(n, dtype=torch.bool, device=env.device)
+    for _ in range(1500):
+        obs, rew, done, _ = env.step(fused(obs[:, :13].contiguous(), deterministic=True)[0])
+        first &= ~done
+        if not bool(first.any()):
+            break
+    assert not bool(first.any())
+    stats = env.episode_stats()                 # R6_STAT_LANDED counts episodes meeting every landing condition
+    assert stats["episodes"] >= n and stats["ground"] > 0.99 * stats["episodes"]
+    frac = stats["landed"] / stats["episodes"]
+    print(f"[shipped policy] {100 * frac:.1f} % of {n} episodes land")
+    assert frac > 0.80
