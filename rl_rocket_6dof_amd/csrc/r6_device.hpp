@@ -221,9 +221,10 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) y1[i] = fmaf(h, kend[i], y0[i]);
     } else {
-        // Classical RK4 as a rolled loop over the four stages (one copy of the RHS in the instruction
-        // stream, register footprint of a single stage):  y1 accumulates y0 + h/6 (k1 + 2k2 + 2k3 + k4),
-        // yt is the stage argument.  Mass is linear in time: stage masses m, m-h/2 mdot (x2), m-h mdot.
+        // Classical RK4, one loop over the four stages (unrolled by default: rolled, ~20 % of the VALU slots went
+        // into register copies at the back edge; R6_RK4_ROLLED=1 keeps one copy of the RHS for experiments):
+        // y1 accumulates y0 + h/6 (k1 + 2k2 + 2k3 + k4), yt is the stage argument.  Mass is linear in time:
+        // stage masses m, m-h/2 mdot (x2), m-h mdot.
         const float hh = 0.5f * h;
         const float h6 = h * (1.0f / 6.0f);
         float yt[kDyn];

@@ -32,9 +32,11 @@ __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) 
 // the tile loop -- each wave owns a private LDS tile for the AoS observation edge -- so the waves of
 // a CU drift apart and their load / compute / store phases overlap.  The hot loop is kept lean so
 // that many waves are resident (occupancy is what hides HBM latency here):
-//   * ground events re-enter the same integrator loop body (no second copy, no extra registers);
+//   * a ground event costs two evaluations of the force/torque half of the RHS (Hermite dense output of the
+//     step, r6_device.hpp integrate<>), not a second RK4 step;
 //   * finished episodes are not re-sampled in the divergent per-lane path: their env indices go to a
-//     per-workgroup LDS queue that is drained densely (all 256 lanes busy) once, after the loop;
+//     per-workgroup LDS queue that is drained densely once, after the loop (a full queue -- mass termination --
+//     makes the excess lanes re-sample in the tile loop);
 //   * kernel parameters are re-read from the kernarg segment per phase instead of living in ~110
 //     SGPRs across the loop.
 // -------------------------------------------------------------------------------------------------
