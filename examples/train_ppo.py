@@ -38,7 +38,9 @@ def main():
                                                  "best_model through SB3's EvalCallback, main_6DOF.py)")
     args = ap.parse_args()
 
-    rank, world, local = r6dist.init_from_env()
+    # R6_DIST_BACKEND=gloo + R6_FORCE_DEVICE=0 rehearse several ranks on ONE GPU (RCCL wants one device per rank)
+    rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
+    local = int(os.environ.get("R6_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     sb3_config, env_config = load_config(args.config)
     max_steps = int(sb3_config["max_time"] / env_config["timestep"])          # main_6DOF.py:31
