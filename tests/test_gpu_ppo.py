@@ -68,3 +68,21 @@ def test_graphed_update_follows_the_eager_update():
     assert float((pe - pg).abs().max()) < 2e-3, float((pe - pg).abs().max())
     for k in ("pg_loss", "v_loss", "approx_kl"):
         assert abs(out[0][1][k] - out[1][1][k]) <= 2e-2 * max(1.0, abs(out[0][1][k])), (k, out[0][1][k], out[1][1][k])
+
+
+def test_ppo_with_the_reference_topology_runs_fused_and_graphed():
+    """PPOConfig(shared_trunk=True, net_arch=(128, 64)) = SB3 1.6's reading of the reference's net_arch=[128, 64]:
+    rollouts go through the fused forward (one trunk), the update through the graphed minibatch step."""
+    import math
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+    from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+    env = BatchedRocket6DOF(4096, default_env_config(), remove_mass=True, clip_reward=(-1, 100), max_episode_steps=1500, seed=11)
+    algo = PPO(env, PPOConfig(n_steps=32, batch_size=1 << 14, n_epochs=3, net_arch=(128, 64), shared_trunk=True, seed=11))
+    assert algo.fused is not None and algo.fused.shared
+    assert sum(p.numel() for p in algo.policy.parameters()) == 10311
+    hist = algo.learn(6 * 32 * 4096)
+    assert algo._graph is not None
+    assert len(hist) == 6 and all(math.isfinite(v) for h in hist for v in h.values())
+    assert sum(h["episodes"] for h in hist) > 1000       # episodes are ~170 steps long: the later rollouts finish some
