@@ -226,24 +226,7 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
         const int n_nets = net.shared ? 1 : 2;   // one trunk feeds both heads, or one MLP per head
 #pragma unroll 1
         for (int nt = 0; nt < n_nets; ++nt) {
-            // ---- layer 1: one K = 16 step per 32-feature block, B = the split obs row ---------------------------
-            f32x16 a1[H1 / 32];
-#pragma unroll
-            for (int mb = 0; mb < H1 / 32; ++mb) {
-                const int f = ((nt * (H1 / 32) + mb) * 64 + lane) * 8;
-                const h8 wh = *(const h8*)&ldsh[Im::oW1h + f], wl = *(const h8*)&ldsh[Im::oW1l + f];
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                a1[mb] = mfma3(wh, wl, xs, z);
-            }
-#pragma unroll
-            for (int mb = 0; mb < H1 / 32; ++mb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[mb][r] = half_sigmoid(a1[mb][r]);
-            }
-
-            // ---- layer 2: accumulators start at the bias; registers 8s..8s+7 of a1[b] are K-step (b, s) ------------
+            // ---- layer 2 accumulators start at the bias -----------------------------------------------------------
             f32x16 a2[H2 / 32];
 #pragma unroll
             for (int mb = 0; mb < H2 / 32; ++mb) {
@@ -256,19 +239,38 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
                     a2[mb][q * 4 + 3] = b[3];
                 }
             }
+            // ---- layer 1 one 32-feature block at a time (one K = 16 step, B = the split obs row), fed straight
+            //      into layer 2 -- registers 8s..8s+7 of the block are K-step (b, s) -- so that a single block of
+            //      layer-1 activations is live instead of H1/32 of them (64 registers less for H1 = 128) ---------
 #pragma unroll
-            for (int g = 0; g < (H1 / 32) * 2; ++g) {      // g = (b, s)
-                float v[8];
+            for (int blk = 0; blk < H1 / 32; ++blk) {
+                f32x16 a1;
+                {
+                    const int f = ((nt * (H1 / 32) + blk) * 64 + lane) * 8;
+                    const h8 wh = *(const h8*)&ldsh[Im::oW1h + f], wl = *(const h8*)&ldsh[Im::oW1l + f];
+                    f32x16 z;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = a1[g >> 1][(g & 1) * 8 + j];
-                const Split bs = split8(v);
-#pragma unroll
-                for (int mb = 0; mb < H2 / 32; ++mb) {
-                    const int f = (((nt * (H2 / 32) + mb) * (H1 / 32) * 2 + g) * 64 + lane) * 8;
-                    const h8 wh = *(const h8*)&ldsh[Im::oW2h + f], wl = *(const h8*)&ldsh[Im::oW2l + f];
-                    a2[mb] = mfma3(wh, wl, bs, a2[mb]);
+                    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                    a1 = mfma3(wh, wl, xs, z);
                 }
-                asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[r] = half_sigmoid(a1[r]);
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = a1[sk * 8 + j];
+                    const Split bs = split8(v);
+                    const int g = blk * 2 + sk;
+#pragma unroll
+                    for (int mb = 0; mb < H2 / 32; ++mb) {
+                        const int f = (((nt * (H2 / 32) + mb) * (H1 / 32) * 2 + g) * 64 + lane) * 8;
+                        const h8 wh = *(const h8*)&ldsh[Im::oW2h + f], wl = *(const h8*)&ldsh[Im::oW2l + f];
+                        a2[mb] = mfma3(wh, wl, bs, a2[mb]);
+                    }
+                    asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one block at a time: do not start the next block's layer 1 early
             }
 
             // ---- r of layer 2, then the last layer on the VALU: this half's 16 rows per block (one uniform
