@@ -8,6 +8,7 @@
  *     my_environment/envs/rocket_env.py:523-524   Rocket6DOF._get_obs    -> r6_observe
  *     my_environment/utils/simulator.py:69-104    Simulator6DOF.step     -> r6_sim_step
  *     my_environment/utils/simulator.py:106-143   Simulator6DOF.RHS      -> r6_rhs
+ *     main_6DOF.py:107-139 / montecarlo_script.py  SB3 policy.forward / predict (the caller of step) -> r6_policy_act
  * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
  *
  * Conventions
@@ -18,7 +19,8 @@
  *   - Return value: 0 = OK, negative = -(hipError_t) or R6_E_*; r6_last_error() gives the text
  *     (thread-local).  No C++ exception crosses the ABI.
  *   - SoA arrays are [rows][ld] float with ld >= n (ld*4 bytes should be a multiple of 16 for
- *     full-width accesses; torch allocations are).  AoS arrays are row-major (n, width).
+ *     full-width accesses; torch allocations are; avoid ld a multiple of 2048: rows 8 KiB-multiples apart
+ *     collide on HBM channels, +3 % per step).  AoS arrays are row-major (n, width).
  *   - State rows (simulator.py:14-28): 0-2 position x,y,z (x = height), 3-5 velocity,
  *     6-9 quaternion (leading scalar), 10-12 body rates, 13 mass.
  */
