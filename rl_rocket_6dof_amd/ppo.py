@@ -40,6 +40,8 @@ class PPOConfig:
     batch_size: int = 1 << 16        # minibatch size (SB3 default 64)
     n_epochs: int = 10
     learning_rate: float = 3e-4
+    final_learning_rate: Optional[float] = None   # linear schedule over learn()'s total_timesteps (SB3 accepts a
+                                                  # callable of the remaining progress; None = constant, its default)
     gamma: float = 0.99
     gae_lambda: float = 0.95
     clip_range: float = 0.2
@@ -184,8 +186,10 @@ class PPO:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         torch.manual_seed(cfg.seed)          # identical initial weights on every rank
         self.policy = (policy or ActorCritic(env.obs_dim, 3, cfg.net_arch, cfg.log_std_init, cfg.shared_trunk)).to(self.device)
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
-                                    capturable=(self.device.type == "cuda" and cfg.graph_update))
+        capt = self.device.type == "cuda" and cfg.graph_update
+        # a tensor learning rate is read by the (graphed) Adam step at replay time, so a schedule can move it
+        lr = torch.tensor(float(cfg.learning_rate), device=self.device) if capt else cfg.learning_rate
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5, capturable=capt)
         self._graph, self._graph_key, self._eager_steps = None, None, 0
         rank = dist.get_rank() if self.world > 1 else 0
         self.gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1000003 * rank)
@@ -339,6 +343,14 @@ class PPO:
 
         history = []
         while self.num_timesteps < total_timesteps:
+            if self.cfg.final_learning_rate is not None:
+                frac = min(self.num_timesteps / max(total_timesteps, 1), 1.0)
+                lr = self.cfg.learning_rate + (self.cfg.final_learning_rate - self.cfg.learning_rate) * frac
+                for g in self.opt.param_groups:
+                    if torch.is_tensor(g["lr"]):
+                        g["lr"].fill_(lr)
+                    else:
+                        g["lr"] = lr
             self.collect_rollouts()
             info = self.train()
             if self.env.stats is not None:
