@@ -367,7 +367,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     const int64_t n_full = n >> 6;  // tiles [0, n_full) are full; tile n_full (if any) is partial
     int tile_no = 0;
 #pragma unroll 1
-    for (int64_t t = t_first; t < n_tiles; t += nw) {
+    for (int64_t ts = t_first; ts < n_tiles; ts += nw) {
+        // Odd steps walk the tiles backwards: what the previous step wrote last is read first, while it is still
+        // in the 256 MB Infinity Cache.  Irrelevant at N = 2^20 (the whole working set fits), 208 -> 159 us per
+        // step at N = 2^22 (800 MB working set: 3.8 -> 5.0 TB/s algorithmic).
+        const int64_t t = (step_index & 1) ? (n_tiles - 1 - ts) : ts;
         if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
         else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
         else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
@@ -483,7 +487,8 @@ __global__ __launch_bounds__(kBlock, R6_V2_WAVES) void step_kernel2(const R6Para
 
     int tile_no = 0;
 #pragma unroll 1
-    for (int64_t t = t_first; t < n_tiles; t += nw) {
+    for (int64_t ts = t_first; ts < n_tiles; ts += nw) {
+        const int64_t t = (step_index & 1) ? (n_tiles - 1 - ts) : ts;   // alternating sweep, see step_kernel
         if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
         else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
         else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
