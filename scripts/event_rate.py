@@ -12,13 +12,14 @@ dev = torch.device("cuda:0")
 n = 1 << 20
 env = BatchedRocket6DOF(n, default_env_config(), device=dev, auto_reset=True, seed=42, record_flags=True)
 gen = torch.Generator(device=dev).manual_seed(1234)
-pool = [(torch.rand((n, 3), generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(8)]
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+pool = [(torch.rand((n, 3), generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(P)]
 env.reset()
-for k in range(400):
-    env.step_async(pool[k % 8])
+for k in range(2000):
+    env.step_async(pool[k % P])
 tot_done = tot_ground = tot_tiles = 0
 for k in range(50):
-    env.step_async(pool[k % 8])
+    env.step_async(pool[k % P])
     f = env.flags.clone()
     d = env.done.clone()
     tot_done += int(d.sum())
