@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from dataclasses import dataclass
 from typing import Optional
 

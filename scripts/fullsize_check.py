@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size sanity (GPU box): N = 2^20, auto-reset rollout; sampled envs checked against the oracle."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import oracle_np as onp

@@ -1,4 +1,4 @@
-import torch, time
+import torch
 dev = "cuda:0"
 n = 1 << 20
 def timed(fn, reps=10):

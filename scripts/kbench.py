@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmark (dev tool, GPU box): interleaved rounds of several step-kernel
 configurations in ONE process; reports median / min launch-to-launch time per step."""
-import argparse, json, os, sys, time
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config

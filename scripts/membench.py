@@ -1,4 +1,4 @@
-import ctypes as C, os, sys, torch
+import ctypes as C, os, torch
 here = os.path.dirname(os.path.abspath(__file__))
 lib = C.CDLL(os.path.join(here, "membench.so"))
 dev = torch.device("cuda:0")

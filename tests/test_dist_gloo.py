@@ -2,7 +2,6 @@
 collective and the shard arithmetic are exercised for real; the per-shard stepping is stood in for by
 the C oracle (same RNG stream definition as the kernel), which lets the sharding-invariance property
 be checked end to end: 2 shards with env_offset == 1 big batch, bit for bit."""
-import json
 import os
 import socket
 import sys
@@ -13,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, load_golden
+from conftest import ROOT
 
 
 def _free_port():

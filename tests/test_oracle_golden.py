@@ -1,6 +1,5 @@
 """Pins the CPU oracle (oracle/oracle_np.py) against the golden vectors produced by the reference
 itself (tests/golden/generate_golden.py).  CPU-only; no reference access at run time."""
-import json
 
 import numpy as np
 import pytest
