@@ -29,6 +29,10 @@ def main():
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--lr-final", type=float, default=None, help="linear learning-rate schedule down to this value")
+    ap.add_argument("--log-std-min", type=float, default=-2.5,
+                    help="floor of the policy's log-std (std >= 0.08); SB3 has none -- pass 'nan' to disable -- but with "
+                         "~10^6 samples per update the std collapses (log-std sum -8 after 2e9 steps) and the late phase "
+                         "of training turns erratic; with the floor every run so far ends above 99 %% landings")
     ap.add_argument("--net-arch", default="128,64", help="main_6DOF.py:113 uses [128, 64]; SB3 default is 64,64")
     ap.add_argument("--separate", action="store_true",
                     help="two separate MLPs instead of SB3 1.6's meaning of a plain-list net_arch (one shared trunk, "
@@ -47,7 +51,7 @@ def main():
     max_steps = int(sb3_config["max_time"] / env_config["timestep"])          # main_6DOF.py:31
     env = r6dist.make_sharded_env(args.envs, env_config, device=f"cuda:{local}", remove_mass=True,
                                   clip_reward=(-1, 100), max_episode_steps=max_steps, seed=env_config["seed"])
-    cfg = PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, n_epochs=args.epochs, learning_rate=args.lr, final_learning_rate=args.lr_final,
+    cfg = PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, n_epochs=args.epochs, learning_rate=args.lr, final_learning_rate=args.lr_final, log_std_min=(None if args.log_std_min != args.log_std_min else args.log_std_min),
                     net_arch=tuple(int(x) for x in args.net_arch.split(",")), shared_trunk=not args.separate,
                     seed=env_config["seed"])
     algo = PPO(env, cfg)

@@ -52,6 +52,9 @@ class PPOConfig:
     net_arch: Sequence[int] = (64, 64)   # SB3 MlpPolicy default; the reference's training run used [128, 64]
     shared_trunk: bool = False           # True = SB3 1.6 semantics of a plain-list net_arch (one trunk, two heads)
     log_std_init: float = 0.0
+    log_std_min: Optional[float] = None   # floor of the policy's log-std, applied after every optimiser step (SB3 has
+                                          # none: with millions of samples per update the std collapses and the late
+                                          # phase of training turns erratic)
     seed: int = 42
     graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
     fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
@@ -289,6 +292,8 @@ class PPO:
         torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
         self.opt.step()
         with torch.no_grad():
+            if cfg.log_std_min is not None:
+                self.policy.log_std.clamp_(min=cfg.log_std_min)
             acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
                                 ((ratio - 1) - (logp - old_logp[mb])).mean()])
 
