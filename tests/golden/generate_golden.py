@@ -25,6 +25,8 @@ What each file pins (reference file:line):
                    the Box like SB3's predict.  The checkpoint tensors are read with
                    torch.load(weights_only=True) -- no pickled code is executed -- and stored in the fixture
                    (they are the reference's data files, 10 k floats each)   (--only g8)
+  g9_shipped_policy_in_reference   the policy trained on the HIP env (examples/policies/) flown in the REFERENCE
+                   env: 16 episodes, terminal states, landing flags   (--only g9)
 """
 from __future__ import annotations
 
@@ -259,7 +261,49 @@ def gen_g8():
     np.savez_compressed(os.path.join(HERE, "g8_closed_loop.npz"), config=np.array(json.dumps(cfg)), meta=_meta(), **out)
 
 
+def gen_g9():
+    """The policy trained on the HIP env (examples/policies/landing_policy_shared_128_64.pt) flown in the REFERENCE env."""
+    import torch
+
+    root = os.path.dirname(os.path.dirname(HERE))
+    sd = torch.load(os.path.join(root, "examples", "policies", "landing_policy_shared_128_64.pt"), map_location="cpu", weights_only=True)
+
+    def forward(obs13):
+        x = torch.as_tensor(obs13, dtype=torch.float32)
+        h = torch.tanh(torch.nn.functional.linear(x, sd["pi.0.weight"], sd["pi.0.bias"]))
+        h = torch.tanh(torch.nn.functional.linear(h, sd["pi.2.weight"], sd["pi.2.bias"]))
+        return torch.nn.functional.linear(h, sd["pi.4.weight"], sd["pi.4.bias"]).numpy()
+
+    Sim, Env, cfg = load_reference()
+    env = Env(**cfg)
+    env.seed(4321)
+    ics, n_steps, terminal, returns, landed = [], [], [], [], []
+    for ep in range(16):
+        obs = env.reset()
+        ics.append(np.array(env.SIM.state, dtype=np.float64))
+        ret = 0.0
+        for k in range(1500):
+            a = np.clip(forward(obs[0:13]), -1.0, 1.0).astype(np.float32)
+            obs, rew, done, info = env.step(a)
+            ret += float(rew)
+            if done:
+                break
+        n_steps.append(k + 1)
+        terminal.append(np.array(env.SIM.state, dtype=np.float64))
+        returns.append(ret)
+        landed.append(float(info["rewards_dict"]["goal_conditions"]) != 0.0)
+    t = np.array(terminal)
+    print("G9 steps", n_steps, "landed", int(np.sum(landed)), "of", len(landed),
+          "| |r_T| mean %.2f m, |v_T| mean %.2f m/s, return mean %.1f" % (np.linalg.norm(t[:, 0:3], axis=1).mean(),
+                                                                        np.linalg.norm(t[:, 3:6], axis=1).mean(), np.mean(returns)))
+    np.savez_compressed(os.path.join(HERE, "g9_shipped_policy_in_reference.npz"), config=np.array(json.dumps(cfg)), meta=_meta(),
+                        ic=np.array(ics), n_steps=np.array(n_steps), terminal=t, ret=np.array(returns), landed=np.array(landed))
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g9":
+        gen_g9()
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g7":
         gen_g7()
         return

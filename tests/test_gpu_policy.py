@@ -236,3 +236,46 @@ def test_shipped_policy_lands(torch_cuda):
     frac = stats["landed"] / stats["episodes"]
     print(f"[shipped policy] {100 * frac:.1f} % of {n} episodes land")
     assert frac > 0.97
+
+
+def test_shipped_policy_lands_in_the_reference_env_and_here_alike(torch_cuda):
+    """Golden G9: the policy that was trained on the HIP env only (examples/policies/) flown in the REFERENCE env
+    (the reference's own Rocket6DOF + Simulator6DOF: scipy RK45, np.roots) -- it lands 16 episodes of 16 there.
+    Here the same initial conditions go through the HIP env + the fused forward: same step count, same terminal
+    state (2e-4 of the normaliser scale), every episode landed."""
+    torch = torch_cuda
+    import json
+    import os
+
+    from tests.conftest import load_golden
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.policy import FusedActorCritic, load_policy
+
+    G = load_golden("g9_shipped_policy_in_reference.npz")
+    assert bool(G["landed"].all()) and len(G["landed"]) == 16
+    cfg = json.loads(str(G["config"]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fused = FusedActorCritic(load_policy(os.path.join(root, "examples", "policies", "landing_policy_shared_128_64.pt")))
+    n = len(G["ic"])
+    env = BatchedRocket6DOF(n, cfg, remove_mass=True, auto_reset=False, record_terms=True)
+    obs = env.set_state(torch.as_tensor(G["ic"], dtype=torch.float32))
+    n_steps, terminal = np.zeros(n, dtype=int), np.zeros((n, 14))
+    landed = np.zeros(n, dtype=bool)
+    alive = np.ones(n, dtype=bool)
+    for k in range(1500):
+        obs, rew, done, _ = env.step(fused(obs.contiguous(), deterministic=True)[0])
+        d = done.cpu().numpy().astype(bool) & alive
+        if d.any():
+            st = env.get_state().cpu().numpy()
+            goal = env.terms[4, :n].cpu().numpy()
+            n_steps[d], terminal[d], landed[d] = k + 1, st[d], goal[d] != 0.0
+            alive &= ~d
+        if not alive.any():
+            break
+    np.testing.assert_array_equal(n_steps, G["n_steps"])
+    assert landed.all()
+    scale = np.array([2400, 2400, 2400, 615, 615, 615, 1.1, 1.1, 1.1, 1.1, 5.2, 5.2, 5.2, 42000.0])
+    err = np.abs(terminal - G["terminal"]) / scale
+    print(f"[G9] 16 of 16 land in the reference env and here; terminal state within {err.max():.2e} of the normaliser scale")
+    assert err.max() < 2e-4
