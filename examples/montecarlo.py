@@ -7,8 +7,9 @@ forward and the env step are one HIP launch each.
 
     python examples/montecarlo.py --checkpoint /path/to/best_model_2bo71j9m.zip --episodes 100000
 
-``--checkpoint`` is a stable-baselines3 PPO zip (only its tensors are read, torch.load(weights_only=True));
-without it a freshly initialised policy is flown (a smoke run).
+``--checkpoint`` is a stable-baselines3 PPO zip (only its tensors are read, torch.load(weights_only=True)),
+``--policy`` a state_dict saved by examples/train_ppo.py; without either the shipped policy
+(examples/policies/landing_policy_shared_128_64.pt) is flown.
 """
 import argparse
 import os
@@ -19,7 +20,6 @@ import torch
 
 from rl_rocket_6dof_amd import BatchedRocket6DOF, load_config
 from rl_rocket_6dof_amd.policy import FusedActorCritic, load_policy, load_sb3_policy
-from rl_rocket_6dof_amd.ppo import ActorCritic
 
 
 def main():
@@ -40,8 +40,8 @@ def main():
         policy = load_sb3_policy(args.checkpoint)
     elif args.policy:
         policy = load_policy(args.policy)
-    else:
-        policy = ActorCritic(13, 3, (128, 64), shared_trunk=True).cuda()
+    else:   # the policy trained by examples/train_ppo.py that ships with the package
+        policy = load_policy(os.path.join(os.path.dirname(os.path.abspath(__file__)), "policies", "landing_policy_shared_128_64.pt"))
     fused = FusedActorCritic(policy)
     env = BatchedRocket6DOF(n, env_config, integrator=args.integrator, auto_reset=True, track_episodes=True,
                             seed=env_config.get("seed", 42))
