@@ -210,3 +210,36 @@ def test_load_sb3_policy_reads_a_checkpoint_zip_tensor_only(tmp_path):
     with torch.no_grad():
         got = pol.pi(torch.as_tensor(obs)).clamp(-1, 1).numpy()
     np.testing.assert_allclose(got, G[f"{tag}_act_every25"][:, 0], rtol=0, atol=2e-6)
+
+
+def test_shipped_policy_lands_in_the_cpu_restatement_of_the_reference():
+    """No GPU needed: the policy trained on the HIP env (examples/policies/) flown through oracle_np.OracleEnv --
+    the numpy/scipy restatement of the reference's env (adaptive RK45 + terminal event + np.roots reward), from the
+    initial conditions of golden G9 -- ends every episode on the step the REFERENCE ended it, landed."""
+    import json
+    import os
+
+    import numpy as np
+    import torch
+
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd.policy import load_policy
+    from tests.conftest import load_golden
+
+    G = load_golden("g9_shipped_policy_in_reference.npz")
+    cfg = json.loads(str(G["config"]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pol = load_policy(os.path.join(root, "examples", "policies", "landing_policy_shared_128_64.pt"), device="cpu")
+    assert pol.shared_trunk
+    for ep in range(4):
+        env = onp.OracleEnv(cfg)
+        obs = env.reset(G["ic"][ep])
+        for k in range(1500):
+            with torch.no_grad():
+                a = pol.pi(torch.as_tensor(obs[:13], dtype=torch.float32)).clamp(-1, 1).numpy()
+            obs, rew, done, info = env.step(a)
+            if done:
+                break
+        assert k + 1 == int(G["n_steps"][ep])
+        assert info["terms"][4] != 0.0, "goal_conditions: the episode must end landed"
+        np.testing.assert_allclose(env.state[:6], G["terminal"][ep][:6], rtol=0, atol=2e-3)
