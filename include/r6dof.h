@@ -204,6 +204,17 @@ int r6_policy_act(const R6PolicyNet *net, const float *obs, int64_t n, float *ac
                   float *value, float *logp, uint64_t seed, uint64_t step_index, uint64_t env_offset,
                   int deterministic, void *stream);
 
+/* SB3 1.6 `PPO.train` minibatch loss (stable_baselines3/ppo/ppo.py, the trainer behind main_6DOF.py:107-139) and
+ * its gradient with respect to the policy outputs, for n samples in one launch:
+ *   loss = -mean(min(A r, A clip(r, 1-c, 1+c))) + ent_coef * (-mean entropy) + vf_coef * mse(ret, value),
+ *   r = exp(logp(action | mean, log_std) - old_logp),  A = (adv - adv_norm[0]) * adv_norm[1]  (adv_norm NULL: A = adv).
+ * Outputs: grad_mean (n,3), grad_value [n]; grad_log_std [3] and stats [8] are ACCUMULATED (zero them first):
+ * stats = {pg_loss, v_loss, entropy, clip_frac, approx_kl, n, -, -}.  All pointers are device pointers. */
+int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std, const float *action,
+                     const float *old_logp, const float *adv, const float *ret, const float *adv_norm, int64_t n,
+                     float clip_range, float vf_coef, float ent_coef, float *grad_mean, float *grad_value,
+                     float *grad_log_std, float *stats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

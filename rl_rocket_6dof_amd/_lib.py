@@ -13,7 +13,7 @@ ABI_VERSION = 3
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_reset",
-           "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act")
+           "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad")
 
 
 class R6Error(RuntimeError):
@@ -51,7 +51,9 @@ def load(path: str | None = None):
     lib.r6_rhs.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
     lib.r6_policy_net_size.restype = C.c_size_t
     lib.r6_policy_act.argtypes = [C.POINTER(R6PolicyNet), vp, i64, vp, vp, vp, vp, u64, u64, u64, C.c_int, vp]
-    for name in ("r6_step", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act"):
+    f32 = C.c_float
+    lib.r6_ppo_loss_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
+    for name in ("r6_step", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):
         getattr(lib, name).restype = C.c_int
     if lib.r6_abi_version() != ABI_VERSION:
         raise ImportError(f"libr6dof.so ABI {lib.r6_abi_version()} != binding ABI {ABI_VERSION}: rebuild")

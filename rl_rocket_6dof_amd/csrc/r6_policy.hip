@@ -421,3 +421,112 @@ extern "C" int r6_policy_act(const R6PolicyNet* net, const float* obs, int64_t n
     r6_internal_set_error("r6_policy_act: supported nets are obs_dim 13|14 with hidden (64,64) or (128,64)");
     return R6_E_BADARG;
 }
+
+// -------------------------------------------------------------------------------------------------
+// PPO minibatch loss and its gradient with respect to the policy outputs, one launch.
+//
+// SB3 1.6 `PPO.train` per minibatch (stable_baselines3/ppo/ppo.py; the reference trains through it,
+// main_6DOF.py:107-139):  ratio = exp(logp - old_logp);  pg = -mean(min(A ratio, A clip(ratio, 1-c, 1+c)));
+// v = mse(returns, values);  ent = -mean(entropy);  loss = pg + ent_coef ent + vf_coef v,  A normalised over the
+// minibatch when `adv_norm` is given ([mean, 1/(std + 1e-8)], device).  In torch this is ~60 elementwise / reduction
+// kernels forward and backward; here each sample is read once and the gradients that the MLPs' backward needs come
+// out directly:
+//   grad_mean (n,3), grad_value [n]   d loss / d (action mean, value) of every sample
+//   grad_log_std [3]                  accumulated (atomicAdd) -- zero it before the launch
+//   stats [8]                         accumulated sums: pg, v, entropy, clip_frac, approx_kl (each already / n), n
+// torch.minimum's tie rule (ratio inside the clip range: both branches equal, gradient flows) is what the
+// `active` mask below reproduces.
+// -------------------------------------------------------------------------------------------------
+namespace r6p {
+
+__global__ __launch_bounds__(256) void ppo_loss_grad_kernel(const float* __restrict__ mean, const float* __restrict__ value,
+                                                            const float* __restrict__ log_std, const float* __restrict__ action,
+                                                            const float* __restrict__ old_logp, const float* __restrict__ adv,
+                                                            const float* __restrict__ ret, const float* __restrict__ adv_norm,
+                                                            const int64_t n, const float clip, const float vf_coef, const float ent_coef,
+                                                            float* __restrict__ grad_mean, float* __restrict__ grad_value,
+                                                            float* __restrict__ grad_log_std, float* __restrict__ stats) {
+    __shared__ float red[8];
+    if (threadIdx.x < 8) red[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const float ls0 = log_std[0], ls1 = log_std[1], ls2 = log_std[2];
+    const float iv0 = __expf(-2.0f * ls0), iv1 = __expf(-2.0f * ls1), iv2 = __expf(-2.0f * ls2);
+    const float a_mean = adv_norm ? adv_norm[0] : 0.0f, a_istd = adv_norm ? adv_norm[1] : 1.0f;
+    const float inv_n = 1.0f / (float)n;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pg, v, clip_frac, kl, dls0, dls1, dls2
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d0 = action[3 * i + 0] - mean[3 * i + 0], d1 = action[3 * i + 1] - mean[3 * i + 1], d2 = action[3 * i + 2] - mean[3 * i + 2];
+        const float q0 = d0 * d0 * iv0, q1 = d1 * d1 * iv1, q2 = d2 * d2 * iv2;
+        const float logp = -0.5f * (q0 + q1 + q2) - (ls0 + ls1 + ls2) - 2.756815599614018f;
+        const float dl = logp - old_logp[i];
+        const float ratio = __expf(dl);
+        const float A = (adv[i] - a_mean) * a_istd;
+        const float s1 = A * ratio, s2 = A * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+        acc[0] += -fminf(s1, s2);
+        const bool active = !((A > 0.0f && ratio > 1.0f + clip) || (A < 0.0f && ratio < 1.0f - clip));
+        const float g_logp = active ? -s1 * inv_n : 0.0f;          // d pg / d logp
+        grad_mean[3 * i + 0] = g_logp * d0 * iv0;
+        grad_mean[3 * i + 1] = g_logp * d1 * iv1;
+        grad_mean[3 * i + 2] = g_logp * d2 * iv2;
+        acc[4] += g_logp * (q0 - 1.0f);
+        acc[5] += g_logp * (q1 - 1.0f);
+        acc[6] += g_logp * (q2 - 1.0f);
+        const float ve = value[i] - ret[i];
+        acc[1] += ve * ve;
+        grad_value[i] = vf_coef * 2.0f * ve * inv_n;
+        acc[2] += (fabsf(ratio - 1.0f) > clip) ? 1.0f : 0.0f;
+        acc[3] += (ratio - 1.0f) - dl;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[0], red[0] * inv_n);
+        atomicAdd(&stats[1], red[1] * inv_n);
+        atomicAdd(&stats[3], red[2] * inv_n);
+        atomicAdd(&stats[4], red[3] * inv_n);
+        // entropy is state-independent: ent = -(sum_i 0.5 + 0.5 ln(2 pi) + log_std_i); its gradient is -ent_coef per component
+        atomicAdd(&grad_log_std[0], red[4]);
+        atomicAdd(&grad_log_std[1], red[5]);
+        atomicAdd(&grad_log_std[2], red[6]);
+        if (blockIdx.x == 0) {
+            atomicAdd(&stats[2], 3.0f * 1.4189385332046727f + ls0 + ls1 + ls2);
+            atomicAdd(&stats[5], (float)n);
+            atomicAdd(&grad_log_std[0], -ent_coef);
+            atomicAdd(&grad_log_std[1], -ent_coef);
+            atomicAdd(&grad_log_std[2], -ent_coef);
+        }
+    }
+}
+
+}  // namespace r6p
+
+extern "C" int r6_ppo_loss_grad(const float* mean, const float* value, const float* log_std, const float* action,
+                                const float* old_logp, const float* adv, const float* ret, const float* adv_norm, int64_t n,
+                                float clip_range, float vf_coef, float ent_coef, float* grad_mean, float* grad_value,
+                                float* grad_log_std, float* stats, void* stream) {
+    if (!mean || !value || !log_std || !action || !old_logp || !adv || !ret || !grad_mean || !grad_value || !grad_log_std || !stats) {
+        r6_internal_set_error("r6_ppo_loss_grad: all pointers except adv_norm are required");
+        return R6_E_BADARG;
+    }
+    if (n <= 0 || n >= ((int64_t)1 << 31)) {
+        r6_internal_set_error("r6_ppo_loss_grad: need 0 < n < 2^31");
+        return R6_E_BADARG;
+    }
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(r6p::ppo_loss_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), mean, value,
+                       log_std, action, old_logp, adv, ret, adv_norm, n, clip_range, vf_coef, ent_coef, grad_mean, grad_value,
+                       grad_log_std, stats);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        r6_internal_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}

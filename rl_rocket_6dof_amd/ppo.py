@@ -56,9 +56,44 @@ class PPOConfig:
                                           # none: with millions of samples per update the std collapses and the late
                                           # phase of training turns erratic)
     seed: int = 42
+    fused_loss: bool = True          # minibatch loss + its gradient w.r.t. the policy outputs as one HIP launch (GPU only)
     graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
     fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
                                      # net shape is supported and the env is on a GPU; torch modules otherwise
+
+
+class _FusedPPOLoss(torch.autograd.Function):
+    """SB3's PPO minibatch loss with the gradient w.r.t. (action mean, value, log_std) from ONE HIP launch
+    (``r6_ppo_loss_grad``) instead of ~60 elementwise / reduction kernels forward and backward.  Returns
+    ``(loss, stats)``; stats = [pg_loss, v_loss, entropy, clip_frac, approx_kl, n, -, -] (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, mean, value, log_std, action, old_logp, adv, ret, adv_norm, clip, vf_coef, ent_coef):
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        mean, value = mean.contiguous(), value.contiguous()
+        action, old_logp, adv, ret = action.contiguous(), old_logp.contiguous(), adv.contiguous(), ret.contiguous()
+        gm, gv = torch.empty_like(mean), torch.empty_like(value)
+        gls = torch.zeros(3, dtype=torch.float32, device=mean.device)
+        stats = torch.zeros(8, dtype=torch.float32, device=mean.device)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        with torch.cuda.device(mean.device):
+            rc = lib.r6_ppo_loss_grad(ptr(mean), ptr(value), ptr(log_std.detach().contiguous()), ptr(action), ptr(old_logp), ptr(adv),
+                                      ptr(ret), ptr(adv_norm), mean.shape[0], float(clip), float(vf_coef), float(ent_coef),
+                                      ptr(gm), ptr(gv), ptr(gls), ptr(stats),
+                                      C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream))
+        _lib.check(rc, "r6_ppo_loss_grad")
+        ctx.save_for_backward(gm, gv, gls)
+        ctx.mark_non_differentiable(stats)
+        return stats[0] - ent_coef * stats[2] + vf_coef * stats[1], stats
+
+    @staticmethod
+    def backward(ctx, g, _g_stats):
+        gm, gv, gls = ctx.saved_tensors
+        return g * gm, g * gv, g * gls, None, None, None, None, None, None, None, None
 
 
 class _TallLinearFn(torch.autograd.Function):
@@ -278,14 +313,21 @@ class PPO:
         cfg = self.cfg
         obs, act, old_logp, adv, ret = flat
         a = adv[mb]
-        if cfg.normalize_advantage and mb.numel() > 1:
-            a = (a - a.mean()) / (a.std() + 1e-8)
-        values, logp, entropy = self.policy.evaluate(obs[mb], act[mb])
-        ratio = torch.exp(logp - old_logp[mb])
-        pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
-        v_loss = torch.nn.functional.mse_loss(ret[mb], values)
-        ent = -entropy.mean()
-        loss = pg + cfg.ent_coef * ent + cfg.vf_coef * v_loss
+        fused = cfg.fused_loss and self.device.type == "cuda"
+        if fused:
+            norm = torch.stack([a.mean(), 1.0 / (a.std() + 1e-8)]) if (cfg.normalize_advantage and mb.numel() > 1) else None
+            mean, values = self.policy._forward(obs[mb])
+            loss, st = _FusedPPOLoss.apply(mean, values, self.policy.log_std, act[mb], old_logp[mb], a, ret[mb], norm,
+                                           cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
+        else:
+            if cfg.normalize_advantage and mb.numel() > 1:
+                a = (a - a.mean()) / (a.std() + 1e-8)
+            values, logp, entropy = self.policy.evaluate(obs[mb], act[mb])
+            ratio = torch.exp(logp - old_logp[mb])
+            pg = -torch.min(a * ratio, a * ratio.clamp(1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+            v_loss = torch.nn.functional.mse_loss(ret[mb], values)
+            ent = -entropy.mean()
+            loss = pg + cfg.ent_coef * ent + cfg.vf_coef * v_loss
         self.opt.zero_grad(set_to_none=False)
         loss.backward()
         self._sync_grads()
@@ -294,8 +336,11 @@ class PPO:
         with torch.no_grad():
             if cfg.log_std_min is not None:
                 self.policy.log_std.clamp_(min=cfg.log_std_min)
-            acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
-                                ((ratio - 1) - (logp - old_logp[mb])).mean()])
+            if fused:
+                acc += st[:5]
+            else:
+                acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
+                                    ((ratio - 1) - (logp - old_logp[mb])).mean()])
 
     def _graphed_step(self, flat, bs):
         """The minibatch step captured once into a HIP graph (static index / stats buffers) and replayed: at

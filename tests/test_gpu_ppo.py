@@ -86,3 +86,48 @@ def test_ppo_with_the_reference_topology_runs_fused_and_graphed():
     assert algo._graph is not None
     assert len(hist) == 6 and all(math.isfinite(v) for h in hist for v in h.values())
     assert sum(h["episodes"] for h in hist) > 1000       # episodes are ~170 steps long: the later rollouts finish some
+
+
+def test_fused_ppo_loss_matches_autograd():
+    """r6_ppo_loss_grad against the torch expression it replaces (SB3 PPO.train): loss, gradients w.r.t. action mean,
+    value and log_std, and the logged statistics; with and without advantage normalisation, ratios well outside
+    the clip range included."""
+    import math
+
+    import torch
+
+    from rl_rocket_6dof_amd.ppo import _FusedPPOLoss
+
+    torch.manual_seed(0)
+    dev = "cuda"
+    for n, norm_adv in ((70001, True), (4096, False)):
+        mean = torch.randn(n, 3, device=dev, requires_grad=True)
+        value = torch.randn(n, device=dev, requires_grad=True)
+        log_std = torch.tensor([-0.4, 0.2, -1.0], device=dev, requires_grad=True)
+        action = (mean + torch.randn(n, 3, device=dev) * log_std.exp()).detach()
+        old_logp = torch.randn(n, device=dev) * 0.5 - 3.0
+        adv, ret = torch.randn(n, device=dev) * 2 + 0.3, torch.randn(n, device=dev)
+        clip, vf, ec = 0.2, 0.5, 0.01
+
+        def ref(mean, value, log_std):
+            var = torch.exp(2 * log_std)
+            logp = (-0.5 * ((action - mean) ** 2 / var + 2 * log_std + math.log(2 * math.pi))).sum(-1)
+            a = (adv - adv.mean()) / (adv.std() + 1e-8) if norm_adv else adv
+            ratio = torch.exp(logp - old_logp)
+            pg = -torch.min(a * ratio, a * ratio.clamp(1 - clip, 1 + clip)).mean()
+            v = torch.nn.functional.mse_loss(ret, value)
+            ent = -(0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum()
+            return pg + ec * ent + vf * v, pg, v, -ent, ((ratio - 1).abs() > clip).float().mean(), ((ratio - 1) - (logp - old_logp)).mean()
+
+        l_ref, pg, v, ent, cf, kl = ref(mean, value, log_std)
+        g_ref = torch.autograd.grad(l_ref, (mean, value, log_std))
+        norm = torch.stack([adv.mean(), 1.0 / (adv.std() + 1e-8)]) if norm_adv else None
+        l_f, st = _FusedPPOLoss.apply(mean, value, log_std, action, old_logp, adv, ret, norm, clip, vf, ec)
+        g_f = torch.autograd.grad(l_f, (mean, value, log_std))
+        assert abs(float(l_f) - float(l_ref)) <= 2e-5 * max(1.0, abs(float(l_ref)))
+        for a, b, name in zip(g_f, g_ref, ("mean", "value", "log_std")):
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-6) + 1e-9, name
+        for got, want in zip(st[:5].tolist(), (pg, v, ent, cf, kl)):
+            assert abs(got - float(want)) <= 3e-5 * max(1.0, abs(float(want)))
+        assert int(st[5]) == n
