@@ -869,7 +869,15 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     const int64_t n_tiles = (b.n + 63) / 64;
     int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
     const int cap = resident_blocks(kernel, slot);
-    if (blocks > cap) blocks = cap;
+    if (blocks > cap) {
+        // Up to ~3 M envs the grid is the resident capacity (persistent waves, ~3-10 tiles each).  Beyond that the
+        // hardware dispatcher balances better than a fixed tile list per wave: two tiles per wave, as many
+        // workgroups as the per-workgroup statistics rows allow (N = 2^22: 4.6 -> 5.1 TB/s algorithmic, 2^23:
+        // 3.8 -> 4.6, 2^24: 3.8 -> 5.1; at 2^20 / 2^21 the resident grid is 4-13 % faster).
+        static const bool pinned = std::getenv("R6_GRID_BLOCKS") != nullptr;
+        const int64_t big = n_tiles / (2 * r6::kWaves);
+        blocks = (!pinned && n_tiles >= 49152 && big > cap) ? (big < R6_MAX_BLOCKS ? big : R6_MAX_BLOCKS) : cap;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
 }
 
