@@ -27,6 +27,7 @@
 // Tile = 32 envs per wave (one MFMA column block); weights live in LDS for the whole (persistent) launch.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -359,16 +360,17 @@ int launch(const R6PolicyNet& net, const float* obs, int64_t n, float* action, f
     auto kernel = policy_act_kernel<H1, H2, OD>;
     constexpr int kBlock = Shape<H1>::kBlock, kWaves = Shape<H1>::kWaves;
     constexpr size_t lds_bytes = sizeof(float) * Image<H1, H2>::kTotalFloats;
-    static bool configured = false;
-    if (!configured) {
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    static std::atomic<bool> configured[16];   // the attribute is a property of (function, device)
+    const int di = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!configured[di].load(std::memory_order_relaxed)) {
         if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             r6_internal_set_error("r6_policy_act: cannot reserve LDS for the weight image");
             return R6_E_BADARG;
         }
-        configured = true;
+        configured[di].store(dev == di, std::memory_order_relaxed);   // devices beyond the table are configured every call
     }
-    int dev = 0, cus = 256, per_cu = 1;
-    (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     (void)hipGetLastError();
