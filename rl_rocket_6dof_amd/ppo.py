@@ -251,6 +251,8 @@ class PPO:
             if self._fusable() and env.obs_dim in (13, 14):
                 self.fused = FusedActorCritic(self.policy, seed=cfg.seed, env_offset=getattr(env, "env_offset", 0))
                 self._act_clip = torch.zeros((n, 3), **f32)
+                self._boot_out = (torch.zeros((n, 3), **f32), torch.zeros((n, 3), **f32), torch.zeros((n,), **f32),
+                                  torch.zeros((n,), **f32))
 
     def _fusable(self) -> bool:
         from .policy import SUPPORTED_ARCHS
@@ -264,8 +266,9 @@ class PPO:
         env, cfg = self.env, self.cfg
         if self._obs is None:
             self._obs = env.reset().clone()
-        for t in range(cfg.n_steps):
-            self.buf_obs[t].copy_(self._obs)
+        T = cfg.n_steps
+        self.buf_obs[0].copy_(self._obs)
+        for t in range(T):
             if self.fused is not None:
                 # one launch: sample, log-prob, value and the Box clip, written straight into the rollout buffer
                 self._rollout_step += 1
@@ -273,21 +276,26 @@ class PPO:
                            out=(self._act_clip, self.buf_act[t], self.buf_val[t], self.buf_logp[t]))
                 clipped = self._act_clip
             else:
-                actions, values, logp = self.policy.act(self._obs, generator=self.gen)
+                actions, values, logp = self.policy.act(self.buf_obs[t], generator=self.gen)
                 self.buf_act[t].copy_(actions)
                 self.buf_val[t].copy_(values)
                 self.buf_logp[t].copy_(logp)
                 clipped = actions.clamp(-1.0, 1.0).contiguous()                  # SB3 clips to the Box
             obs, rew, done, _ = env.step(clipped)
-            rew = rew.clone()
+            rew_t = self.buf_rew[t]
+            rew_t.copy_(rew)                  # env.obs / rew / done are overwritten by the next step
             if env.max_episode_steps and env.flags is not None and env.final_obs is not None:
                 trunc = (env.flags & FLAG_TRUNCATED) != 0          # TimeLimit.truncated -> bootstrap
-                if bool(trunc.any()):
+                if self.fused is not None:
+                    # no host decision (a .any() would drain the queue every step): V(final_obs) for every env in
+                    # one fused launch, masked by the truncation flag; rows of envs that did not end are ignored
+                    self.fused(env.final_obs, deterministic=True, step_index=0, out=self._boot_out)
+                    rew_t.addcmul_(self._boot_out[2], trunc.to(torch.float32), value=cfg.gamma)
+                elif bool(trunc.any()):
                     idx = trunc.nonzero(as_tuple=True)[0]
-                    rew[idx] += cfg.gamma * self.policy.value(env.final_obs[idx])
-            self.buf_rew[t].copy_(rew)
-            self.buf_done[t].copy_(done.to(torch.float32))
-            self._obs = obs.clone()           # env.obs is overwritten by the next step
+                    rew_t[idx] += cfg.gamma * self.policy.value(env.final_obs[idx])
+            self.buf_done[t].copy_(done)
+            (self.buf_obs[t + 1] if t + 1 < T else self._obs).copy_(obs)
         self.num_timesteps += cfg.n_steps * env.num_envs * self.world
         last_values = self.policy.value(self._obs)
         adv, ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done, last_values, cfg.gamma, cfg.gae_lambda)
