@@ -68,6 +68,21 @@ __device__ __forceinline__ gptr<T> uniform_ptr(T* p) {
     return (gptr<T>)p;  // global address space: selected as global_* with an SGPR base
 }
 
+// Streaming outputs: obs / reward / done are never read back by the step.  Once the working set (189 B/env) is far
+// beyond the 256 MB Infinity Cache, storing them with the non-temporal hint keeps the cache for the state rows the
+// next launch re-reads: A/B at 2^23 envs 334 -> 290 us, at 2^24 766 -> 659 us; 2^21 / 2^22 +-0; at 2^20 (everything
+// fits) +0.3 us.  NT is a template parameter of the kernel (chosen by the launcher from n): as a launch-uniform
+// branch the hint cost the wrapped variant 1.7 us of perturbed code even when off.  (The hint on the one-shot action
+// read costs 5 us: its three 12 B-strided loads per lane live on L1 hits.)
+#ifndef R6_NT_MIN_ENVS
+#define R6_NT_MIN_ENVS (3ll << 21)
+#endif
+template <bool NT, typename T, typename V>
+__device__ __forceinline__ void stream_store(gptr<T> p, V v) {
+    if constexpr (NT) __builtin_nontemporal_store((T)v, p);
+    else *p = (T)v;
+}
+
 // The kernel parameters live in the kernarg segment.  Reading them through a pointer that is
 // re-laundered per phase of the tile loop makes the compiler issue the scalar loads where the
 // values are used (a handful of s_load_dwordxN per phase, scalar-cache hits) instead of hoisting all
@@ -151,7 +166,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #endif
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
-template <int INTEG, int SHAPING, int OD>
+template <int INTEG, int SHAPING, int OD, bool NT = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
@@ -274,8 +289,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
                 if constexpr (INTEG == R6_RK4) return load_buffers();
                 else return b;
             }();
-            uniform_ptr(bs.reward + e0)[ln] = rew;
-            uniform_ptr(bs.done + e0)[ln] = done ? 1 : 0;
+            stream_store<NT>(uniform_ptr(bs.reward + e0) + ln, rew);
+            stream_store<NT>(uniform_ptr(bs.done + e0) + ln, done ? 1 : 0);
             float* row = bs.state + e0;
 #pragma unroll
             for (int j = 0; j < kDyn; ++j) {
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
 #pragma unroll
                 for (int k = 0; k < (n4 + 63) / 64; ++k) {
                     const int q = ln + 64 * k;
-                    if (q < n4) *(gptr<f4>)(dst + 4 * q) = ld4(&tile[4 * q]);
+                    if (q < n4) stream_store<NT>((gptr<f4>)(dst + 4 * q), ld4(&tile[4 * q]));
                 }
             } else {
                 for (int k = ln; k < (int)rem * OD; k += 64) dst[k] = tile[k];
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(kBlock, R6_V2_WAVES) void step_kernel2(const R6Para
 #pragma unroll
                 for (int k = 0; k < (n4 + 63) / 64; ++k) {
                     const int q = lane + 64 * k;
-                    if (q < n4) *(gptr<f4>)(dst + 4 * q) = ld4(&tile[4 * q]);
+                    if (q < n4) stream_store<false>((gptr<f4>)(dst + 4 * q), ld4(&tile[4 * q]));
                 }
             } else {
                 for (int k = lane; k < (int)rem * OD; k += 64) dst[k] = tile[k];
@@ -865,7 +880,10 @@ int resident_blocks(K kernel, int slot) {
 template <int INTEG, int SHAPING, int OD>
 void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
     auto kernel = r6::step_kernel<INTEG, SHAPING, OD>;
-    const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);
+    if constexpr (INTEG != R6_RK45) {   // non-temporal output stores for working sets far beyond the Infinity Cache
+        if (b.n >= R6_NT_MIN_ENVS) kernel = r6::step_kernel<INTEG, SHAPING, OD, true>;
+    }
+    const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);   // both forms share launch bounds and occupancy
     const int64_t n_tiles = (b.n + 63) / 64;
     int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
     const int cap = resident_blocks(kernel, slot);

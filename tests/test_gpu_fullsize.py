@@ -119,6 +119,38 @@ def test_determinism_and_sharding_invariance(torch_cuda, cfg):
     assert torch.equal(full.done[N // 2:], hi.done)
 
 
+def test_streaming_store_form_matches_the_plain_form(torch_cuda, cfg):
+    """From 3 * 2^21 envs on the launcher picks the kernel form whose obs / reward / done stores carry the
+    non-temporal hint (r6_kernels.hip, stream_store).  One batch of that size against its two half-size shards
+    (plain form, global env indices via env_offset): every output bit for bit, resets included."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n = 3 << 21
+    h = n // 2
+    for integ, dt in (("rk4", 0.1), ("euler", 0.04)):
+        big = BatchedRocket6DOF(n, cfg, integrator=integ, timestep=dt, seed=9)
+        lo = BatchedRocket6DOF(h, cfg, integrator=integ, timestep=dt, seed=9, env_offset=0)
+        hi = BatchedRocket6DOF(h, cfg, integrator=integ, timestep=dt, seed=9, env_offset=h)
+        for e in (big, lo, hi):
+            e.reset()
+        g = torch.Generator(device=big.device).manual_seed(4)
+        steps = 150 if integ == "rk4" else 60
+        for k in range(steps):
+            a = torch.rand((n, 3), generator=g, device=big.device) * 2 - 1
+            big.step_async(a)
+            lo.step_async(a[:h].contiguous())
+            hi.step_async(a[h:].contiguous())
+        torch.cuda.synchronize()
+        if integ == "rk4":
+            assert int(big.episode_stats(clear=False)["episodes"]) > 1000
+        assert torch.equal(big.state[:, :h], lo.state[:, :h]) and torch.equal(big.state[:, h:n], hi.state[:, :h])
+        assert torch.equal(big.obs[:h], lo.obs) and torch.equal(big.obs[h:], hi.obs)
+        assert torch.equal(big.reward[:h], lo.reward) and torch.equal(big.reward[h:], hi.reward)
+        assert torch.equal(big.done[:h], lo.done) and torch.equal(big.done[h:], hi.done)
+        del big, lo, hi
+
+
 def test_physical_invariants_over_a_rollout(torch_cuda, cfg):
     """Mass falls by exactly thrust*dt/(g0*Isp) per step (closed form, simulator.py:140-141), the roll
     rate omega_x is conserved (tau_x == 0 and Jy == Jz), observations are state/normaliser."""
