@@ -74,6 +74,9 @@ __device__ __forceinline__ gptr<T> uniform_ptr(T* p) {
 // fits) +0.3 us.  NT is a template parameter of the kernel (chosen by the launcher from n): as a launch-uniform
 // branch the hint cost the wrapped variant 1.7 us of perturbed code even when off.  (The hint on the one-shot action
 // read costs 5 us: its three 12 B-strided loads per lane live on L1 hits.)
+#ifndef R6_OBS_BATCH
+#define R6_OBS_BATCH 1
+#endif
 #ifndef R6_NT_MIN_ENVS
 #define R6_NT_MIN_ENVS (3ll << 21)
 #endif
@@ -162,7 +165,8 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #define R6_RK4_WAVES 5
 #endif
 #ifndef R6_EULER_WAVES
-#define R6_EULER_WAVES 4   // room for the register prefetch of the next tile (see the tile loop)
+#define R6_EULER_WAVES 5   // 90 VGPRs with the register prefetch of the next tile; a budget of 4 waves lets the allocator
+                           // drift past 96 and silently lose the fifth wave (34.2 -> 34.9 us when that happened)
 #endif
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
@@ -236,8 +240,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         // `ln` = the lane id again, opaque to the optimiser: everything addressed after the integration is
         // re-derived from it here instead of being hoisted out of the tile loop and kept in VGPRs across
         // the RK4 stages (where the register budget of 5 waves/SIMD is decided).
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        // (masked to 6 bits after the laundering: with a known-small unsigned index the stores below take the
+        // SGPR-base + 32-bit-VGPR-offset form instead of a 64-bit VALU address add each.)
+        unsigned lnu = lane;
+        asm volatile("" : "+v"(lnu));
+        const int ln = (INTEG == R6_EULER) ? (int)lnu : (int)(lnu & 63u);   // Euler: A/B says the VALU-address form (+0.5 us with the mask)
 
         // ---- termination (env:213, :591-593), reward (env:215, :228-229, :317-402),
         //      fused ClipReward / TimeLimit / Monitor (main_6DOF.py:33-51).  In the RK4 instances the
@@ -351,11 +358,22 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         {
             const gptr<float> dst = uniform_ptr(((INTEG == R6_RK4) ? load_buffers().obs : b.obs) + e0 * OD);
             if constexpr (FULL) {
-                constexpr int n4 = 64 * OD / 4;
+                // 64 * OD / 4 float4 chunks: three full rounds of 64 lanes (all LDS reads first, then the stores) and
+                // a tail of 32 (OD 14) or 16 (OD 13) lanes
+                constexpr int n4 = 64 * OD / 4, kRounds = n4 / 64, kTail = n4 - 64 * kRounds;
+#if R6_OBS_BATCH
+                f4 v[kRounds];
 #pragma unroll
-                for (int k = 0; k < (n4 + 63) / 64; ++k) {
-                    const int q = ln + 64 * k;
-                    if (q < n4) stream_store<NT>((gptr<f4>)(dst + 4 * q), ld4(&tile[4 * q]));
+                for (int k = 0; k < kRounds; ++k) v[k] = ld4(&tile[4 * (ln + 64 * k)]);
+#pragma unroll
+                for (int k = 0; k < kRounds; ++k) stream_store<NT>((gptr<f4>)(dst + 4 * (ln + 64 * k)), v[k]);
+#else
+#pragma unroll
+                for (int k = 0; k < kRounds; ++k) stream_store<NT>((gptr<f4>)(dst + 4 * (ln + 64 * k)), ld4(&tile[4 * (ln + 64 * k)]));
+#endif
+                if (kTail > 0 && ln < kTail) {
+                    const int q = ln + 64 * kRounds;
+                    stream_store<NT>((gptr<f4>)(dst + 4 * q), ld4(&tile[4 * q]));
                 }
             } else {
                 for (int k = ln; k < (int)rem * OD; k += 64) dst[k] = tile[k];
