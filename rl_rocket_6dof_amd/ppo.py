@@ -323,7 +323,10 @@ class PPO:
         a = adv[mb]
         fused = cfg.fused_loss and self.device.type == "cuda"
         if fused:
-            norm = torch.stack([a.mean(), 1.0 / (a.std() + 1e-8)]) if (cfg.normalize_advantage and mb.numel() > 1) else None
+            norm = None
+            if cfg.normalize_advantage and mb.numel() > 1:
+                std, mean = torch.std_mean(a)                      # one Welford pass instead of two reductions
+                norm = torch.stack([mean, 1.0 / (std + 1e-8)])
             mean, values = self.policy._forward(obs[mb])
             loss, st = _FusedPPOLoss.apply(mean, values, self.policy.log_std, act[mb], old_logp[mb], a, ret[mb], norm,
                                            cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
@@ -336,7 +339,7 @@ class PPO:
             v_loss = torch.nn.functional.mse_loss(ret[mb], values)
             ent = -entropy.mean()
             loss = pg + cfg.ent_coef * ent + cfg.vf_coef * v_loss
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)   # fresh gradient buffers: no fill + accumulate-add launch per parameter (graph-safe: replays reuse the pool addresses)
         loss.backward()
         self._sync_grads()
         torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
