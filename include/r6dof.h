@@ -134,8 +134,9 @@ typedef struct R6Buffers {
     uint32_t *fin_length; /* [n]       out at done: episode length */
     uint8_t *nfev;        /* [n]       out: RHS evaluations of the step (scipy sol.nfev), saturating at 255 */
     float *stats;         /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out: per-workgroup running sums over
-                                       finished episodes (see R6_STAT_*); no float atomics; the
-                                       caller sums the rows */
+                                       finished episodes (see R6_STAT_*): accumulated with LDS float
+                                       atomics inside a workgroup, then added to the workgroup's own row
+                                       (no global atomics); the caller sums the rows */
 } R6Buffers;
 
 int r6_abi_version(void);
@@ -199,7 +200,9 @@ size_t r6_policy_net_size(void); /* sizeof(R6PolicyNet) */
  *   value [n], logp [n]  state value, log-probability of raw_action          (NULL to skip)
  * Gaussian noise: Philox4x32-10 keyed by (seed, step_index, env_offset + i) + Box-Muller, so a rollout
  * does not depend on sharding; `deterministic` != 0 returns the mean action (`model.predict(...,
- * deterministic=True)`, montecarlo_script.py).  fp32 arithmetic on the matrix cores (exact-fp32 MFMA). */
+ * deterministic=True)`, montecarlo_script.py).  fp32-accurate arithmetic on the matrix cores: every fp32 operand is
+ * split into an f16 hi + lo pair (v_mfma_f32_32x32x16_f16, three products per K-step, fp32 accumulation; agrees
+ * with torch fp32 to 2e-5). */
 int r6_policy_act(const R6PolicyNet *net, const float *obs, int64_t n, float *action, float *raw_action,
                   float *value, float *logp, uint64_t seed, uint64_t step_index, uint64_t env_offset,
                   int deterministic, void *stream);

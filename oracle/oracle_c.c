@@ -274,11 +274,13 @@ void oc_reset_sample(const OcParams *p, uint64_t seed, uint64_t gid, uint64_t st
  * Rocket6DOF.step (env:201-231) for n envs, array-of-structs float64 state.
  *   state (n,14) in/out; epconst (n,2) in/out = m0, v0; action (n,3) f32; obs (n,14) f32; reward (n) f64;
  *   done (n) u8; flags (n) u8 (1 ground, 2 bounds, 4 truncated); terms (n,7) f64 or NULL;
- *   ep_step (n) u32 / ep_return (n) f64 in/out or NULL; final_obs (n,14) f32 or NULL.
+ *   ep_step (n) u32 / ep_return (n) f64 in/out or NULL; final_obs (n,14) f32 or NULL;
+ *   fin_return (n) f64 / fin_length (n) u32 or NULL: return and length of the episode that ended in this step
+ *   (what gym's Monitor reports, main_6DOF.py:51), written for done envs only.
  */
 void oc_env_step(const OcParams *p, double *state, double *epconst, const float *action, float *obs, double *reward,
                  uint8_t *done, uint8_t *flags, double *terms, uint32_t *ep_step, double *ep_return, float *final_obs,
-                 uint64_t seed, uint64_t step_index, uint64_t env_offset, int64_t n) {
+                 double *fin_return, uint32_t *fin_length, uint64_t seed, uint64_t step_index, uint64_t env_offset, int64_t n) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double *y = state + i * NS;
@@ -304,6 +306,10 @@ void oc_env_step(const OcParams *p, double *state, double *epconst, const float 
         if (flags) flags[i] = (uint8_t)((status ? 1 : 0) | (bnd ? 2 : 0) | (trunc ? 4 : 0));
         if (terms) memcpy(terms + 7 * i, t7, sizeof(t7));
         for (int j = 0; j < NS; ++j) obs[i * NS + j] = (float)(y[j] / p->norm[j]); /* env:503-504 */
+        if (dn && ep_step) {
+            if (fin_return) fin_return[i] = ep_return[i];
+            if (fin_length) fin_length[i] = ep_step[i];
+        }
         if (dn && p->auto_reset) {
             if (final_obs) memcpy(final_obs + i * NS, obs + i * NS, NS * sizeof(float));
             float ic[NS];

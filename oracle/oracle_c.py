@@ -50,7 +50,7 @@ def load(build: bool = True):
     lib.oc_sim_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int]
     lib.oc_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     lib.oc_reset_sample.argtypes = [C.POINTER(OcParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
-    lib.oc_env_step.argtypes = [C.POINTER(OcParams)] + [C.c_void_p] * 11 + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]
+    lib.oc_env_step.argtypes = [C.POINTER(OcParams)] + [C.c_void_p] * 13 + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64]
     assert lib.oc_params_size() == C.sizeof(OcParams), (lib.oc_params_size(), C.sizeof(OcParams))
     _lib = lib
     return lib
@@ -106,6 +106,8 @@ class BatchOracle:
         self.final_obs = np.zeros((n, NS), np.float32)
         self.ep_step = np.zeros(n, np.uint32) if track else None
         self.ep_return = np.zeros(n) if track else None
+        self.fin_return = np.zeros(n) if track else None
+        self.fin_length = np.zeros(n, np.uint32) if track else None
         self.step_count = 0
 
     def set_state(self, states, m0=None, v0=None):
@@ -125,7 +127,8 @@ class BatchOracle:
         self.step_count += 1
         self.lib.oc_env_step(C.byref(self.p), _vp(self.state), _vp(self.epconst), _vp(a), _vp(self.obs), _vp(self.reward),
                              _vp(self.done), _vp(self.flags), _vp(self.terms), _vp(self.ep_step), _vp(self.ep_return),
-                             _vp(self.final_obs), self.seed, self.step_count, self.env_offset, self.n)
+                             _vp(self.final_obs), _vp(self.fin_return), _vp(self.fin_length), self.seed, self.step_count,
+                             self.env_offset, self.n)
         return self.obs, self.reward, self.done
 
 

@@ -37,3 +37,11 @@ def register():
     from .compat import register_gym_id
 
     return register_gym_id(ENV_ID, f"{__name__}.rocket_env:Rocket6DOF")
+
+
+# my_environment/__init__.py:4-7 of the reference registers the id when the package is imported; so does this one
+# whenever a gym registry is importable (a no-op otherwise -- gym is not a dependency).
+try:
+    register()
+except Exception:  # pragma: no cover - registration must never break the import
+    pass

@@ -65,7 +65,9 @@ def load(path: str | None = None):
     return lib
 
 
-def check(rc: int, what: str = "r6"):
+def check(rc: int, what: str = "r6", lib=None):
+    """Raises R6Error for a non-zero return code.  ``lib`` = the handle the failing call went through (the error
+    text is thread-local state of THAT library instance; A/B builds loaded side by side each have their own)."""
     if rc != 0:
-        msg = load().r6_last_error().decode(errors="replace")
+        msg = (lib if lib is not None else load()).r6_last_error().decode(errors="replace")
         raise R6Error(f"{what} failed (rc={rc}): {msg}")

@@ -16,13 +16,14 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from typing import Any, List, Optional, Sequence
 
 import numpy as np
 import torch
 
 from . import _lib
-from .compat import Box
+from .compat import Box, VecEnv
 from .params import (ACTION_DIM, MAX_BLOCKS, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS, STATE_DIM,
                      STAT_NAMES, R6Buffers, default_env_config, make_params)
 
@@ -49,31 +50,52 @@ def _leading_dim(n: int) -> int:
     return ld + 1024 if ld % 2048 == 0 else ld
 
 
+class StaleInfosError(RuntimeError):
+    pass
+
+
 class LazyInfos(Sequence):
     """``infos`` of one step: behaves like SB3's list of N dicts, but dicts are built on access and
     the device data is copied to the host once, on first access (N = 2^20 dicts per step would
-    dominate everything otherwise)."""
+    dominate everything otherwise).
+
+    The snapshot is taken from the env's live output buffers, which the NEXT step overwrites: an ``infos`` object
+    belongs to the step that returned it.  Indexing it for the first time after the env has stepped again raises
+    ``StaleInfosError`` instead of silently reporting the later step; call ``materialize()`` right after ``step``
+    to keep an ``infos`` beyond its step (one device->host copy)."""
 
     def __init__(self, env: "BatchedRocket6DOF"):
         self._env = env
         self._host = None
+        self._step = env._step_count
 
     def __len__(self):
         return self._env.num_envs
 
+    def materialize(self) -> "LazyInfos":
+        self._snapshot()
+        return self
+
     def _snapshot(self):
         if self._host is None:
             e = self._env
+            if e._step_count != self._step:
+                raise StaleInfosError(
+                    f"infos of step {self._step} first read after step {e._step_count}: the env's output buffers "
+                    "now hold the later step; index infos before stepping again or call infos.materialize()")
             h = {"done": e.done.cpu().numpy().astype(bool)}
             h["flags"] = e.flags.cpu().numpy() if e.flags is not None else None
             idx = np.nonzero(h["done"])[0]
             h["done_idx"] = {int(k): j for j, k in enumerate(idx)}
+            h["final_obs"] = h["fin_return"] = h["fin_length"] = None
             if len(idx) and e.auto_reset:
                 sel = torch.as_tensor(idx, device=e.device)
                 h["final_obs"] = e.final_obs[sel].cpu().numpy()
-                h["fin_return"] = e.fin_return[sel].cpu().numpy()
-                h["fin_length"] = e.fin_length[sel].cpu().numpy()
+                if e.fin_return is not None and e.fin_length is not None:   # None when episode tracking is off
+                    h["fin_return"] = e.fin_return[sel].cpu().numpy()
+                    h["fin_length"] = e.fin_length[sel].cpu().numpy()
             h["terms"] = e.terms[:, : e.num_envs].cpu().numpy() if e.terms is not None else None
+            h["t"] = round(time.time() - e._t_start, 6)
             self._host = h
         return self._host
 
@@ -101,12 +123,17 @@ class LazyInfos(Sequence):
         if h["done"][i] and e.auto_reset:
             j = h["done_idx"][i]
             info["terminal_observation"] = h["final_obs"][j]           # SB3 DummyVecEnv
-            info["episode"] = {"r": float(h["fin_return"][j]), "l": int(h["fin_length"][j])}  # SB3 Monitor
+            if h["fin_return"] is not None:                            # gym Monitor (main_6DOF.py:51): r, l, t
+                info["episode"] = {"r": float(h["fin_return"][j]), "l": int(h["fin_length"][j]), "t": h["t"]}
         return info
 
 
-class BatchedRocket6DOF:
-    """N Rocket6DOF environments on one MI355X; see module docstring."""
+class BatchedRocket6DOF(VecEnv):
+    """N Rocket6DOF environments on one MI355X; see module docstring.
+
+    Derives from ``stable_baselines3.common.vec_env.VecEnv`` whenever SB3 is importable (``compat.VecEnv``), so
+    SB3's ``isinstance(env, VecEnv)`` check takes it unwrapped; without SB3 the base is a stand-in with the same
+    constructor contract and helpers."""
 
     metadata = {"render.modes": []}
 
@@ -131,7 +158,6 @@ class BatchedRocket6DOF:
             self.env_config, integrator=integrator, n_substeps=n_substeps, timestep=timestep,
             remove_mass=remove_mass, clip_reward=clip_reward, max_episode_steps=max_episode_steps,
             auto_reset=auto_reset, reward_annealing=reward_annealing, vertical_attitude_reward=vertical_attitude_reward)
-        self.num_envs = int(num_envs)
         self.obs_dim = int(self.params.obs_dim)
         self.auto_reset = bool(auto_reset)
         self.max_episode_steps = int(max_episode_steps)
@@ -140,8 +166,11 @@ class BatchedRocket6DOF:
         self._seed = int(self.spec.seed if seed is None else seed)
         self.term_names = TERM_NAMES_ACC if self.spec.shaping_type == "acceleration" else TERM_NAMES_VEL
 
-        self.observation_space = Box(low=-1, high=1, shape=(self.obs_dim,))   # rocket_env.py:137, wrappers.py:123
-        self.action_space = Box(low=-1, high=1, shape=(ACTION_DIM,))          # rocket_env.py:147
+        VecEnv.__init__(self, int(num_envs),
+                        Box(low=-1, high=1, shape=(self.obs_dim,), dtype=np.float32),   # rocket_env.py:137, wrappers.py:123
+                        Box(low=-1, high=1, shape=(ACTION_DIM,), dtype=np.float32))     # rocket_env.py:147
+        self.remove_mass, self.clip_reward = bool(remove_mass), clip_reward
+        self._t_start = time.time()
         self.reward_coefficients = self.spec.reward_coefficients
         self.state_normalizer = self.spec.state_normalizer
         self.timestep = float(self.params.dt)
@@ -209,7 +238,7 @@ class BatchedRocket6DOF:
         with torch.cuda.device(self.device):
             rc = self.lib.r6_reset(C.byref(self.params), C.byref(self._buf), _ptr(m), self._seed,
                                    _EXPLICIT_RESET_BASE + self._reset_count, self.env_offset, self._stream())
-        _lib.check(rc, "r6_reset")
+        _lib.check(rc, "r6_reset", self.lib)
         self._reset_count += 1
         if m is not None:
             torch.cuda.current_stream(self.device).synchronize()  # keep `m` alive until consumed
@@ -229,7 +258,7 @@ class BatchedRocket6DOF:
         with torch.cuda.device(self.device):
             rc = self.lib.r6_step(C.byref(self.params), C.byref(self._buf), self._seed, self._step_count,
                                   self.env_offset, self._stream())
-        _lib.check(rc, "r6_step")
+        _lib.check(rc, "r6_step", self.lib)
         self._pending = a   # keeps the action tensor alive until step_wait
 
     def step_wait(self):
@@ -258,7 +287,7 @@ class BatchedRocket6DOF:
             self.ep_return.zero_()
         with torch.cuda.device(self.device):
             rc = self.lib.r6_observe(C.byref(self.params), C.byref(self._buf), self._stream())
-        _lib.check(rc, "r6_observe")
+        _lib.check(rc, "r6_observe", self.lib)
         return self._out(self.obs)
 
     def terminal_errors(self) -> dict:
@@ -307,7 +336,12 @@ class BatchedRocket6DOF:
         return [out] * len(self._indices(indices))
 
     def env_is_wrapped(self, wrapper_class, indices=None) -> List[bool]:
-        return [False] * len(self._indices(indices))
+        """True for the wrappers of the reference's make_env() stack (main_6DOF.py:44-53) whose fused equivalent is
+        switched on -- e.g. SB3's evaluate_policy asks for ``Monitor`` and then reads ``info["episode"]``."""
+        name = getattr(wrapper_class, "__name__", str(wrapper_class))
+        fused = {"Monitor": self.fin_return is not None, "TimeLimit": self.max_episode_steps > 0,
+                 "RemoveMassFromObs": self.remove_mass, "ClipReward": self.clip_reward is not None}
+        return [bool(fused.get(name, False))] * len(self._indices(indices))
 
     def _indices(self, indices):
         if indices is None:

@@ -2,6 +2,7 @@
 a GPU).  ``python -m rl_rocket_6dof_amd.build`` or ``__graft_entry__.build()``."""
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -11,7 +12,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libr6dof.so")
 SOURCES = ["r6_kernels.hip", "r6_policy.hip"]
-HEADERS = ["r6_device.hpp", os.path.join("..", "..", "include", "r6dof.h")]
+
+
+def _headers():
+    """Every header a source can include: csrc/*.hpp, csrc/*.h and include/*.h."""
+    inc = os.path.join(HERE, "..", "include")
+    return sorted(glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                  glob.glob(os.path.join(inc, "*.h")))
+
+
 ARCH = "gfx950"
 
 
@@ -26,7 +35,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

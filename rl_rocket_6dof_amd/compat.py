@@ -71,12 +71,57 @@ class _Env:
 Box = _spaces.Box if _spaces is not None else _Box
 Env = _gym.Env if _gym is not None else _Env
 
-try:  # pragma: no cover
+class _VecEnv:
+    """Stand-in for ``stable_baselines3.common.vec_env.VecEnv`` (SB3 1.6 public API) used when SB3 is not
+    importable: the constructor contract ``VecEnv.__init__(num_envs, observation_space, action_space)`` and the
+    concrete helpers SB3 code calls on any VecEnv (``step``, ``unwrapped``, ``getattr_depth_check``,
+    ``_get_indices``).  The abstract part (reset / step_async / step_wait / close / get_attr / set_attr /
+    env_method / env_is_wrapped / seed) is implemented by the subclass."""
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def get_images(self):
+        raise NotImplementedError
+
+    def render(self, mode="human"):
+        raise NotImplementedError
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def getattr_depth_check(self, name, already_found):
+        if hasattr(self, name) and already_found:
+            return f"{type(self).__module__}.{type(self).__name__}"
+        return None
+
+    def _get_indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, int):
+            return [indices]
+        return indices
+
+
+try:  # pragma: no cover - depends on the environment
     from stable_baselines3.common.vec_env import VecEnv as _SB3VecEnv
     HAVE_SB3 = True
 except Exception:  # pragma: no cover
     _SB3VecEnv = None
     HAVE_SB3 = False
+
+# Base class of BatchedRocket6DOF: the real SB3 VecEnv whenever SB3 is importable, so that SB3's
+# ``isinstance(env, VecEnv)`` checks (BaseAlgorithm._wrap_env) take the env as it is.
+VecEnv = _SB3VecEnv if _SB3VecEnv is not None else _VecEnv
 
 
 def register_gym_id(env_id: str, entry_point: str) -> bool:

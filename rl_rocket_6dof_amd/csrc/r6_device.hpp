@@ -145,16 +145,48 @@ __device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
     return R;
 }
 
+#ifndef R6_OPT_ROT
+#define R6_OPT_ROT 1   // 1: rotate the two vectors with the quaternion directly; 0: through the 3x3 matrix (A/B switch)
+#endif
+
 // sim:106-143 -- the force / torque half of the RHS: dv[3] = d(v)/dt, dw[2] = d(omega_y, omega_z)/dt
 // (d(omega_x)/dt == 0, see below); `im` = 1 / mass at this time.
+//
+// Only two rotated vectors are needed per evaluation -- R T_B (thrust in the inertial frame) and the body-frame y, z
+// components of the velocity (aero torque arm is along body x) -- so the matrix of sim:189-199 is not formed: with
+// s = 2 / |q|^2 (scipy normalises the quaternion, sim:198),  R u = u + s q_v x (q_v x u + q0 u)  and
+// R^T u = u - s q_v x (q0 u - q_v x u)  (6 multiply-adds less per evaluation than 9 matrix entries + 5 dot products).
 __device__ __forceinline__ void rhs_dyn(const float (&y)[kDyn], float im, const Control& c, const Inertia& J,
                                         float (&dv)[3], float (&dw)[2]) {
     const float vx = y[3], vy = y[4], vz = y[5];
-    const Rot R = rotmat(y[6], y[7], y[8], y[9]);
-
-    // aero (sim:216-219): A_B = -k rho |v| R^T v ; rotated back: A_I = -k rho |v| v
     const float speed = fsqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+    // aero (sim:216-219): A_B = -k rho |v| R^T v ; rotated back: A_I = -k rho |v| v
     const float ca = -kAeroK * density(y[0]) * speed;
+#if R6_OPT_ROT
+    const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
+    const float n2 = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, q3 * q3)));
+    const float s = 2.0f * frcp(n2);
+    // thrust: e = q_v x T_B + q0 T_B,  R T_B = T_B + s q_v x e
+    const float ex = fmaf(q2, c.tbz, fmaf(-q3, c.tby, q0 * c.tbx));
+    const float ey = fmaf(q3, c.tbx, fmaf(-q1, c.tbz, q0 * c.tby));
+    const float ez = fmaf(q1, c.tby, fmaf(-q2, c.tbx, q0 * c.tbz));
+    const float tix = fmaf(s, fmaf(q2, ez, -q3 * ey), c.tbx);
+    const float tiy = fmaf(s, fmaf(q3, ex, -q1 * ez), c.tby);
+    const float tiz = fmaf(s, fmaf(q1, ey, -q2 * ex), c.tbz);
+    // body-frame velocity, y and z components: d = q0 v - q_v x v,  R^T v = v - s q_v x d
+    const float dx = fmaf(q0, vx, fmaf(q3, vy, -q2 * vz));
+    const float dy = fmaf(q0, vy, fmaf(q1, vz, -q3 * vx));
+    const float dz = fmaf(q0, vz, fmaf(q2, vx, -q1 * vy));
+    const float vby = fmaf(-s, fmaf(q3, dx, -q1 * dz), vy);
+    const float vbz = fmaf(-s, fmaf(q1, dy, -q2 * dx), vz);
+    const float aby = ca * vby;   // body-y aero force
+    const float abz = ca * vbz;   // body-z aero force
+    // translational (sim:124-130, :156-165): F_I = R T_B + A_I
+    dv[0] = fmaf(fmaf(ca, vx, tix), im, -(float)kG0);
+    dv[1] = fmaf(ca, vy, tiy) * im;
+    dv[2] = fmaf(ca, vz, tiz) * im;
+#else
+    const Rot R = rotmat(y[6], y[7], y[8], y[9]);
     const float aby = ca * fmaf(R.r01, vx, fmaf(R.r11, vy, R.r21 * vz));  // body-y aero force
     const float abz = ca * fmaf(R.r02, vx, fmaf(R.r12, vy, R.r22 * vz));  // body-z aero force
 
@@ -165,6 +197,7 @@ __device__ __forceinline__ void rhs_dyn(const float (&y)[kDyn], float im, const 
     dv[0] = fmaf(fx, im, -(float)kG0);
     dv[1] = fy * im;
     dv[2] = fz * im;
+#endif
 
     // rotational (sim:137, :232-244): tau = r_T x T_B + r_cp x A_B with r = [rx,0,0]
     //   -> tau = (0, -rT*tbz - rcp*abz, rT*tby + rcp*aby);  J = diag(Jx,Jt,Jt):
@@ -210,6 +243,10 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Co
 #ifndef R6_RK4_ROLLED
 #define R6_RK4_ROLLED 0
 #endif
+#ifndef R6_OPT_PK
+#define R6_OPT_PK 0   // A/B switch: slope combination of the RK4 stages as packed fp32 (v_pk_fma_f32)
+#endif
+typedef float pf2 __attribute__((ext_vector_type(2)));
 
 // One application of the Euler / RK4 map.
 template <int INTEG>
@@ -227,6 +264,45 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
         // stage masses m, m-h/2 mdot (x2), m-h mdot.
         const float hh = 0.5f * h;
         const float h6 = h * (1.0f / 6.0f);
+#if R6_OPT_PK
+        // The 24 multiply-adds per stage that combine the slopes (12 live components x {accumulate, next argument}) are
+        // pairwise independent: held as float2 they issue as 12 v_pk_fma_f32 (1.3 issue slots per pair instead of 2).
+        constexpr int kPairs = 6;
+        constexpr int kIdx[kPairs][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {11, 12}};   // omega_x (10) is constant
+        pf2 y0p[kPairs], y1p[kPairs];
+        float yt[kDyn];
+#pragma unroll
+        for (int j = 0; j < kPairs; ++j) {
+            y0p[j] = pf2{y0[kIdx[j][0]], y0[kIdx[j][1]]};
+            y1p[j] = y0p[j];
+        }
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) yt[i] = y0[i];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float tm = (s == 0) ? 0.0f : ((s == 3) ? h : hh);
+            const float w = (s == 0 || s == 3) ? h6 : 2.0f * h6;
+            const float an = (s == 2) ? h : hh;
+            rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, kend);
+            const pf2 wp = pf2{w, w}, anp = pf2{an, an};
+#pragma unroll
+            for (int j = 0; j < kPairs; ++j) {
+                const pf2 kp = pf2{kend[kIdx[j][0]], kend[kIdx[j][1]]};
+                y1p[j] = __builtin_elementwise_fma(wp, kp, y1p[j]);
+                if (s < 3) {
+                    const pf2 a = __builtin_elementwise_fma(anp, kp, y0p[j]);
+                    yt[kIdx[j][0]] = a.x;
+                    yt[kIdx[j][1]] = a.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPairs; ++j) {
+            y1[kIdx[j][0]] = y1p[j].x;
+            y1[kIdx[j][1]] = y1p[j].y;
+        }
+        y1[10] = y0[10];
+#else
         float yt[kDyn];
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) {
@@ -250,6 +326,7 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
                 yt[i] = fmaf(an, kend[i], y0[i]);
             }
         }
+#endif
     }
 }
 
@@ -301,14 +378,17 @@ __device__ __forceinline__ float poly_root01(const float (&c)[N], float x0, floa
 // EVENTS = true : full semantics, returns status (1 = ground event handled).
 // EVENTS = false: the crossing sub-step stops the integration with status 1 WITHOUT producing the event
 //                 state (timing experiments only).
-template <int INTEG, bool EVENTS>
+template <int INTEG, bool EVENTS, bool ONE = false>
 __device__ __forceinline__ int integrate(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J,
                                          float dt, int nsub) {
-    const float h = dt / (float)nsub;
+    // ONE: the caller guarantees nsub == 1 (the reference's own configuration: one env step = one integrator call).
+    // The general form carries the state across a loop back edge, which costs ~25 register copies per sub-step
+    // (y0 and y1 are both live until the end of the RK4 map); the single-step form is straight-line code.
+    const float h = ONE ? dt : dt / (float)nsub;
     int status = 0;
 #pragma unroll 1
-    for (int s = 0; s < nsub; ++s) {
-        if (status != 0) continue;
+    for (int s = 0; s < (ONE ? 1 : nsub); ++s) {
+        if (!ONE && status != 0) continue;
         float y1[kDyn];
         float hs = h;
         step_map<INTEG>(y, mass, c, J, h, y1);

@@ -1,10 +1,13 @@
 // r6_kernels.hip -- HIP kernels (gfx950) + the C ABI of include/r6dof.h.
 //
-// Launch shape: one lane per environment, 256-lane workgroups (4 wave64), grid = ceil(n/256)
-// (N = 2^20 -> 4096 workgroups >> 256 CUs).  State is structure-of-arrays, so every state access is
-// a fully coalesced 256 B per wave-instruction.  The two array-of-structures edges -- actions
-// (n,3) in, observations (n,13|14) out -- go through an LDS tile per workgroup so that global
-// memory only ever sees contiguous 16 B-per-lane accesses.  No MFMA: there is no contraction here.
+// Launch shape of the step: one lane per environment, 256-lane workgroups (4 wave64), a PERSISTENT grid sized to
+// the resident capacity of the chip (occupancy x 256 CUs); every wave walks over 64-env tiles on its own, with
+// no workgroup barrier in the tile loop.  State is structure-of-arrays, so every state access is a fully
+// coalesced 256 B per wave-instruction with a wave-uniform SGPR base.  The two array-of-structures edges:
+// observations (n,13|14) leave through a per-WAVE LDS tile as contiguous 16 B-per-lane stores; actions (n,3)
+// are read directly at a 12 B lane stride (the wave touches the same 768 B three times, the repeats are L1
+// hits; an LDS-staged variant was measured and is not faster).  No MFMA: there is no
+// contraction here.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -15,7 +18,6 @@
 #include <type_traits>
 
 #include "r6_device.hpp"
-#include "r6_device_pk.hpp"
 
 namespace r6 {
 
@@ -161,6 +163,9 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
     }
 }
 
+#ifndef R6_DISABLE_ONE
+#define R6_DISABLE_ONE 0   // A/B switch (scripts/build_variant.sh): 1 = always the general sub-step loop
+#endif
 #ifndef R6_RK4_WAVES
 #define R6_RK4_WAVES 5
 #endif
@@ -170,7 +175,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #endif
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
-template <int INTEG, int SHAPING, int OD, bool NT = false>
+template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
@@ -232,8 +237,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         if constexpr (INTEG == R6_RK45) {
             status = integrate_rk45(y, mass, c, J, p.dt, nfev);
         } else {
-            status = integrate<INTEG, true>(y, mass, c, J, p.dt, p.n_substeps);
-            nfev = (INTEG == R6_RK4 ? 4 : 1) * p.n_substeps;
+            status = integrate<INTEG, true, ONE>(y, mass, c, J, p.dt, p.n_substeps);
+            nfev = (INTEG == R6_RK4 ? 4 : 1) * (ONE ? 1 : p.n_substeps);
         }
 #endif
 
@@ -491,289 +496,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
 }
 
 // -------------------------------------------------------------------------------------------------
-// Rocket6DOF.step, two environments per lane (fixed-step integrators).
-//
-// Same contract and same outputs as step_kernel; what changes is the work a lane carries: envs e0 + 2 lane and
-// e0 + 2 lane + 1 of a 128-env tile, their state as float2 values.  The dynamics (r6_device_pk.hpp) then issue as
-// packed fp32 instructions and every SoA row access is one 8-byte load / store per lane; a prototype of exactly
-// this (scripts/protobench.hip: the step's memory pattern + RK4) runs at the memory floor, 31 us per 2^20 envs,
-// where the one-env-per-lane form of the same prototype needs the integration on top.  Reward, termination,
-// episode bookkeeping and the event root are control flow per env: they stay scalar (r6_device.hpp) and are
-// applied to the two halves in turn.  256 registers per lane (2 waves per SIMD), 128-env tiles.
-// -------------------------------------------------------------------------------------------------
-#ifndef R6_V2_WAVES
-#define R6_V2_WAVES 2
-#endif
-constexpr int kTile2 = 128;
-
-template <int INTEG, int SHAPING, int OD>
-__global__ __launch_bounds__(kBlock, R6_V2_WAVES) void step_kernel2(const R6Params p, const R6Buffers b, const uint64_t seed,
-                                                          const uint64_t step_index, const uint64_t env_offset) {
-    using pk::f2;
-    __shared__ __attribute__((aligned(16))) float tiles[kWaves][kTile2 * OD];
-    __shared__ float lds_inv_norm[R6_STATE_DIM];
-    __shared__ int rq[kResetQueueCap];
-    __shared__ int rq_count;
-    __shared__ float blk_stats[R6_NUM_STATS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* tile = tiles[wave];
-    const int64_t n = b.n;
-    const int64_t n_tiles = (n + kTile2 - 1) / kTile2;
-    const int64_t nw = (int64_t)gridDim.x * kWaves;
-    const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
-    const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
-
-    if (tid == 0) rq_count = 0;
-    if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
-    if (tid < R6_STATE_DIM) {
-        const kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-        lds_inv_norm[tid] = ((const __attribute__((address_space(4))) float*)(k + offsetof(R6Params, inv_norm)))[tid];
-    }
-    __syncthreads();
-
-    int tile_no = 0;
-#pragma unroll 1
-    for (int64_t ts = t_first; ts < n_tiles; ts += nw) {
-        const int64_t t = (step_index & 1) ? (n_tiles - 1 - ts) : ts;   // alternating sweep, see step_kernel
-        if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
-        else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
-        else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-        ++tile_no;
-
-        const int64_t e0 = t * kTile2;
-        const int64_t rem = n - e0;
-        const bool full = rem >= kTile2;
-        const bool live[2] = {full || 2 * lane < rem, full || 2 * lane + 1 < rem};
-        const int64_t ld = b.ld;
-
-        // ---- inputs -----------------------------------------------------------------------------------------------
-        f2 y[kDyn], mass, m0, v0 = pk::splat(0.0f), ep_ret = pk::splat(0.0f);
-        float act[2][3];
-        uint32_t ep_step[2] = {0u, 0u};
-        if (full) {
-            const float* row = b.state + e0;
-#pragma unroll
-            for (int j = 0; j < kDyn; ++j) {
-                y[j] = ((gptr<const f2>)uniform_ptr(row))[lane];
-                row += ld;
-            }
-            mass = ((gptr<const f2>)uniform_ptr(row))[lane];
-            m0 = ((gptr<const f2>)uniform_ptr(b.epconst + e0))[lane];
-            if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = ((gptr<const f2>)uniform_ptr(b.epconst + (ld + e0)))[lane];
-            if (has_ep) {
-                const u2 es = ((gptr<const u2>)uniform_ptr(b.ep_step + e0))[lane];
-                ep_step[0] = es.x;
-                ep_step[1] = es.y;
-                ep_ret = ((gptr<const f2>)uniform_ptr(b.ep_return + e0))[lane];
-            }
-            const gptr<const f2> a2p = (gptr<const f2>)uniform_ptr(b.action + e0 * R6_ACTION_DIM);   // 6 floats per lane
-            const f2 q0 = a2p[3 * lane + 0], q1 = a2p[3 * lane + 1], q2 = a2p[3 * lane + 2];
-            act[0][0] = q0.x; act[0][1] = q0.y; act[0][2] = q1.x;
-            act[1][0] = q1.y; act[1][1] = q2.x; act[1][2] = q2.y;
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float yy[R6_STATE_DIM];
-#pragma unroll
-                for (int j = 0; j < R6_STATE_DIM; ++j) yy[j] = (j == 0) ? 1000.0f : ((j == 6) ? 1.0f : ((j == 13) ? 4.0e4f : 0.0f));
-                float mm = 4.0e4f, vv = 0.0f, er = 0.0f;
-                act[h][0] = act[h][1] = 0.0f;
-                act[h][2] = -1.0f;
-                if (live[h]) {
-                    const int64_t i = e0 + 2 * lane + h;
-#pragma unroll
-                    for (int j = 0; j < R6_STATE_DIM; ++j) yy[j] = b.state[j * ld + i];
-                    mm = b.epconst[i];
-                    if constexpr (SHAPING == R6_SHAPING_VELOCITY) vv = b.epconst[ld + i];
-                    if (has_ep) {
-                        ep_step[h] = b.ep_step[i];
-                        er = b.ep_return[i];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) act[h][c] = b.action[i * R6_ACTION_DIM + c];
-                }
-#pragma unroll
-                for (int j = 0; j < kDyn; ++j) y[j][h] = yy[j];
-                mass[h] = yy[13];
-                m0[h] = mm;
-                v0[h] = vv;
-                ep_ret[h] = er;
-            }
-        }
-
-        // ---- dynamics, packed (sim:69-143) ---------------------------------------------------------------------------
-        const Control c0 = make_control_normalised(p, act[0][0], act[0][1], act[0][2]);
-        const Control c1 = make_control_normalised(p, act[1][0], act[1][1], act[1][2]);
-        const pk::Control2 c2 = pk::pack(c0, c1);
-        const pk::Inertia2 J2 = pk::pack(make_inertia(m0.x), make_inertia(m0.y));
-        int status[2];
-        pk::integrate<INTEG>(y, mass, c2, J2, p.dt, p.n_substeps, status);
-        const int nfev = (INTEG == R6_RK4 ? 4 : 1) * p.n_substeps;
-
-        // ---- per env: termination, reward, fused wrappers (scalar code, one half after the other) ------------------
-        float rew[2];
-        bool done[2], bnd[2], truncated[2] = {false, false}, landed[2];
-        {
-            const R6Params pr = load_params();
-            const bool opt_terms = b.terms != nullptr;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float yh[kDyn];
-#pragma unroll
-                for (int j = 0; j < kDyn; ++j) yh[j] = y[j][h];
-                const Control& ch = h ? c1 : c0;
-                bnd[h] = bounds_violation(pr, yh[0], yh[1], yh[2]);
-                done[h] = (status[h] != 0) || bnd[h];
-                RewardOut rw = reward<SHAPING>(pr, yh, mass[h], ch, v0[h]);
-                landed[h] = rw.landed;
-                rew[h] = finalize_reward(pr, rw, bnd[h], fmaf(2.0f * ch.thrust, frcp(pr.max_thrust), -1.0f), yh);
-                if (live[h] && opt_terms) {
-                    const R6Buffers bo = load_buffers();
-                    float* trow = bo.terms + (e0 + 2 * lane + h);
-#pragma unroll
-                    for (int q = 0; q < R6_NUM_TERMS; ++q) {
-                        *trow = rw.terms[q];
-                        trow += bo.ld;
-                    }
-                }
-                if (pr.clip_reward) rew[h] = fminf(fmaxf(rew[h], pr.clip_lo), pr.clip_hi);
-                ep_step[h] += 1u;
-                ep_ret[h] += rew[h];
-                if (pr.max_episode_steps > 0 && ep_step[h] >= (uint32_t)pr.max_episode_steps) {
-                    truncated[h] = !done[h];
-                    done[h] = true;
-                }
-            }
-        }
-
-        // ---- outputs ---------------------------------------------------------------------------------------------------
-        {
-            const R6Buffers bs = load_buffers();
-            auto flag_of = [&](int h) {
-                return (uint8_t)((status[h] == 1 ? R6_FLAG_GROUND : 0) | (bnd[h] ? R6_FLAG_BOUNDS : 0) | (truncated[h] ? R6_FLAG_TRUNCATED : 0));
-            };
-            if (full) {
-                ((gptr<f2>)uniform_ptr(bs.reward + e0))[lane] = f2{rew[0], rew[1]};
-                ((gptr<uint16_t>)uniform_ptr(bs.done + e0))[lane] = (uint16_t)((done[0] ? 1 : 0) | ((done[1] ? 1 : 0) << 8));
-                float* row = bs.state + e0;
-#pragma unroll
-                for (int j = 0; j < kDyn; ++j) {
-                    ((gptr<f2>)uniform_ptr(row))[lane] = y[j];
-                    row += bs.ld;
-                }
-                ((gptr<f2>)uniform_ptr(row))[lane] = mass;
-                if (has_ep) {
-                    ((gptr<u2>)uniform_ptr(bs.ep_step + e0))[lane] = u2{ep_step[0], ep_step[1]};
-                    ((gptr<f2>)uniform_ptr(bs.ep_return + e0))[lane] = ep_ret;
-                }
-                if (bs.flags) ((gptr<uint16_t>)uniform_ptr(bs.flags + e0))[lane] = (uint16_t)(flag_of(0) | (flag_of(1) << 8));
-                if (bs.nfev) ((gptr<uint16_t>)uniform_ptr(bs.nfev + e0))[lane] = (uint16_t)((nfev > 255 ? 255 : nfev) * 0x0101);
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (!live[h]) continue;
-                    const int64_t i = e0 + 2 * lane + h;
-                    bs.reward[i] = rew[h];
-                    bs.done[i] = done[h] ? 1 : 0;
-#pragma unroll
-                    for (int j = 0; j < kDyn; ++j) bs.state[j * bs.ld + i] = y[j][h];
-                    bs.state[13 * bs.ld + i] = mass[h];
-                    if (has_ep) {
-                        bs.ep_step[i] = ep_step[h];
-                        bs.ep_return[i] = ep_ret[h];
-                    }
-                    if (bs.flags) bs.flags[i] = flag_of(h);
-                    if (bs.nfev) bs.nfev[i] = (uint8_t)(nfev > 255 ? 255 : nfev);
-                }
-            }
-        }
-
-        // ---- observation (env:503-504): registers -> LDS row-major tile of 128 rows ---------------------------------
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int j = 0; j < kDyn; ++j) {
-                if (j < OD) tile[(2 * lane + h) * OD + j] = y[j][h] * lds_inv_norm[j];
-            }
-            if (OD == 14) tile[(2 * lane + h) * OD + (OD - 1)] = mass[h] * lds_inv_norm[13];
-        }
-
-        // ---- finished episodes: terminal outputs now, re-sampling deferred to the dense pass --------------------------
-        bool overflow[2] = {false, false};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (live[h] && done[h]) {
-                const R6Buffers bb = load_buffers();
-                if (bb.stats) {
-                    atomicAdd(&blk_stats[R6_STAT_EPISODES], 1.0f);
-                    atomicAdd(&blk_stats[R6_STAT_RETURN], ep_ret[h]);
-                    atomicAdd(&blk_stats[R6_STAT_RETURN_SQ], ep_ret[h] * ep_ret[h]);
-                    atomicAdd(&blk_stats[R6_STAT_LENGTH], (float)ep_step[h]);
-                    if (status[h] == 1) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
-                    if (bnd[h]) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
-                    if (truncated[h]) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
-                    if (landed[h]) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
-                }
-                if (p.auto_reset) {
-                    const int64_t i = e0 + 2 * lane + h;
-                    if (bb.final_obs) {
-#pragma unroll
-                        for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = tile[(2 * lane + h) * OD + j];
-                    }
-                    if (bb.fin_return) bb.fin_return[i] = ep_ret[h];
-                    if (bb.fin_length) bb.fin_length[i] = ep_step[h];
-                    const int slot = atomicAdd(&rq_count, 1);
-                    if (slot < kResetQueueCap) rq[slot] = (int)i;
-                    else overflow[h] = true;
-                }
-            }
-        }
-
-        // ---- LDS tile -> contiguous 16 B-per-lane stores of the (128, OD) observation block ---------------------------
-        wave_lds_sync();
-        {
-            const gptr<float> dst = uniform_ptr(load_buffers().obs + e0 * OD);
-            if (full) {
-                constexpr int n4 = kTile2 * OD / 4;
-#pragma unroll
-                for (int k = 0; k < (n4 + 63) / 64; ++k) {
-                    const int q = lane + 64 * k;
-                    if (q < n4) stream_store<false>((gptr<f4>)(dst + 4 * q), ld4(&tile[4 * q]));
-                }
-            } else {
-                for (int k = lane; k < (int)rem * OD; k += 64) dst[k] = tile[k];
-            }
-        }
-        wave_lds_sync();
-
-        if (__builtin_expect(__any(overflow[0] || overflow[1]), 0)) {   // reset queue full (mass termination)
-            __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (overflow[h]) reset_env_global<OD>(load_params(), load_buffers(), e0 + 2 * lane + h, seed, step_index, env_offset);
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    __syncthreads();
-    const int n_queued = rq_count;
-    if (n_queued > 0) {
-        const R6Buffers bb = load_buffers();
-        if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
-        const R6Params pp = load_params();
-        const int n_rec = n_queued < kResetQueueCap ? n_queued : kResetQueueCap;
-        for (int k = tid; k < n_rec; k += kBlock) reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
-    } else if (!p.auto_reset) {
-        const R6Buffers bb = load_buffers();
-        if (bb.stats && tid < R6_NUM_STATS && blk_stats[0] > 0.0f) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // Rocket6DOF.reset (env:180-199) for masked envs.
 // -------------------------------------------------------------------------------------------------
 template <int OD>
@@ -898,8 +620,12 @@ int resident_blocks(K kernel, int slot) {
 template <int INTEG, int SHAPING, int OD>
 void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
     auto kernel = r6::step_kernel<INTEG, SHAPING, OD>;
-    if constexpr (INTEG != R6_RK45) {   // non-temporal output stores for working sets far beyond the Infinity Cache
-        if (b.n >= R6_NT_MIN_ENVS) kernel = r6::step_kernel<INTEG, SHAPING, OD, true>;
+    if constexpr (INTEG != R6_RK45) {
+        // ONE: n_substeps == 1 (the reference's configuration) gets the straight-line integrator instance;
+        // NT: non-temporal output stores for working sets far beyond the Infinity Cache
+        const bool nt = b.n >= R6_NT_MIN_ENVS;
+        if (p.n_substeps == 1 && !R6_DISABLE_ONE) kernel = nt ? r6::step_kernel<INTEG, SHAPING, OD, true, true> : r6::step_kernel<INTEG, SHAPING, OD, false, true>;
+        else if (nt) kernel = r6::step_kernel<INTEG, SHAPING, OD, true, false>;
     }
     const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);   // both forms share launch bounds and occupancy
     const int64_t n_tiles = (b.n + 63) / 64;
@@ -917,42 +643,8 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
 }
 
-// Two-envs-per-lane kernel: needs 8-byte aligned rows (even pitch, 8-byte aligned bases).
-inline bool aligned_to(const void* p, uintptr_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
-
-bool step2_applicable(const R6Buffers& b) {
-    static const int mode = [] {
-        const char* e = std::getenv("R6_STEP_V2");   // 1 = two envs per lane (packed fp32), 0 = one env per lane
-        return e ? std::atoi(e) : 0;
-    }();
-    if (mode == 0) return false;
-    return (b.ld % 2 == 0) && aligned_to(b.state, 8) && aligned_to(b.epconst, 8) && aligned_to(b.reward, 8) &&
-           aligned_to(b.ep_step, 8) && aligned_to(b.ep_return, 8) && aligned_to(b.done, 2) && aligned_to(b.flags, 2) &&
-           aligned_to(b.nfev, 2);
-}
-
-template <int INTEG, int SHAPING, int OD>
-void launch_step2_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
-    auto kernel = r6::step_kernel2<INTEG, SHAPING, OD>;
-    const int slot = 12 + INTEG * 2 + SHAPING;   // INTEG in {0, 1}: slots 12..15 (OD shares the occupancy)
-    const int64_t n_tiles = (b.n + r6::kTile2 - 1) / r6::kTile2;
-    int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
-    const int cap = resident_blocks(kernel, slot);
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
-}
-
 template <int INTEG, int SHAPING>
 void launch_step_od(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
-    if constexpr (INTEG != R6_RK45) {
-        if (step2_applicable(b)) {
-            if (p.obs_dim == 14)
-                launch_step2_inst<INTEG, SHAPING, 14>(p, b, seed, step, off, s);
-            else
-                launch_step2_inst<INTEG, SHAPING, 13>(p, b, seed, step, off, s);
-            return;
-        }
-    }
     if (p.obs_dim == 14)
         launch_step_inst<INTEG, SHAPING, 14>(p, b, seed, step, off, s);
     else

@@ -77,7 +77,7 @@ class FusedActorCritic:
             rc = self.lib.r6_policy_act(C.byref(net), obs.data_ptr(), n, act.data_ptr(), raw.data_ptr(), val.data_ptr(),
                                         logp.data_ptr(), self.seed, step, self.env_offset, int(bool(deterministic)),
                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        _lib.check(rc, "r6_policy_act")
+        _lib.check(rc, "r6_policy_act", self.lib)
         return act, raw, val, logp
 
     __call__ = forward

@@ -85,7 +85,7 @@ class _FusedPPOLoss(torch.autograd.Function):
                                       ptr(ret), ptr(adv_norm), mean.shape[0], float(clip), float(vf_coef), float(ent_coef),
                                       ptr(gm), ptr(gv), ptr(gls), ptr(stats),
                                       C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream))
-        _lib.check(rc, "r6_ppo_loss_grad")
+        _lib.check(rc, "r6_ppo_loss_grad", lib)
         ctx.save_for_backward(gm, gv, gls)
         ctx.mark_non_differentiable(stats)
         return stats[0] - ent_coef * stats[2] + vf_coef * stats[1], stats
@@ -232,6 +232,27 @@ class PPO:
         rank = dist.get_rank() if self.world > 1 else 0
         self.gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1000003 * rank)
         n, T = env.num_envs, cfg.n_steps
+        if getattr(env, "max_episode_steps", 0) and (getattr(env, "flags", None) is None or getattr(env, "final_obs", None) is None):
+            # without the truncation flag and the terminal observation the time-limit bootstrap gamma * V(s_T) cannot
+            # be applied and truncated episodes would silently count as true terminations
+            raise ValueError("PPO needs env.flags and env.final_obs when max_episode_steps > 0: build the env with "
+                             "record_flags=True and auto_reset=True")
+        # Shards may be ragged (dist.shard_range hands out counts that differ by one).  Everything a collective depends
+        # on is agreed ONCE here: the number of minibatch steps per epoch (the minimum over ranks, so every rank issues
+        # the same number of gradient all-reduces) and each rank's weight in the gradient average (its share of the
+        # samples of a global minibatch).
+        self.local_envs = n
+        total = T * n
+        self._bs = min(cfg.batch_size, total)
+        self._steps_per_epoch = total // self._bs
+        self.global_envs, self._grad_weight = n, 1.0
+        if self.world > 1:
+            t = torch.zeros((self.world, 3), dtype=torch.float64)
+            t[rank] = torch.tensor([n, self._bs, self._steps_per_epoch], dtype=torch.float64)
+            t = self._all_reduce(t)
+            self.global_envs = int(t[:, 0].sum())
+            self._grad_weight = float(self._bs / t[:, 1].sum())
+            self._steps_per_epoch = int(t[:, 2].min())
         f32 = dict(dtype=torch.float32, device=self.device)
         self.buf_obs = torch.zeros((T, n, env.obs_dim), **f32)
         self.buf_act = torch.zeros((T, n, 3), **f32)
@@ -253,6 +274,16 @@ class PPO:
                 self._act_clip = torch.zeros((n, 3), **f32)
                 self._boot_out = (torch.zeros((n, 3), **f32), torch.zeros((n, 3), **f32), torch.zeros((n,), **f32),
                                   torch.zeros((n,), **f32))
+
+    def _all_reduce(self, t: torch.Tensor, op=None) -> torch.Tensor:
+        """Sum (default) over ranks of a small host tensor: through the device for RCCL, on the host for gloo."""
+        op = dist.ReduceOp.SUM if op is None else op
+        if dist.get_backend() == "nccl":
+            d = t.to(self.device)
+            dist.all_reduce(d, op=op)
+            return d.cpu()
+        dist.all_reduce(t, op=op)
+        return t
 
     def _fusable(self) -> bool:
         from .policy import SUPPORTED_ARCHS
@@ -296,7 +327,7 @@ class PPO:
                     rew_t[idx] += cfg.gamma * self.policy.value(env.final_obs[idx])
             self.buf_done[t].copy_(done)
             (self.buf_obs[t + 1] if t + 1 < T else self._obs).copy_(obs)
-        self.num_timesteps += cfg.n_steps * env.num_envs * self.world
+        self.num_timesteps += cfg.n_steps * self.global_envs     # the whole job, ragged shards included
         last_values = self.policy.value(self._obs)
         adv, ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done, last_values, cfg.gamma, cfg.gae_lambda)
         self.adv.copy_(adv)      # persistent buffers: the graphed update step reads these addresses
@@ -306,11 +337,13 @@ class PPO:
         if self.world == 1:
             return
         grads = [p.grad for p in self.policy.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])          # one bucket: ~10^4 parameters
+        # one bucket (~10^4 parameters); each rank's gradient (a mean over ITS minibatch) enters with its share of the
+        # global minibatch's samples, so the result is the mean over all samples also when shards are ragged
+        flat = torch.cat([g.reshape(-1) for g in grads]) * self._grad_weight
         if dist.get_backend() != "nccl":
             flat = flat.cpu()
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat = flat.to(grads[0].device) / self.world
+        flat = flat.to(grads[0].device)
         off = 0
         for g in grads:
             g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -374,14 +407,14 @@ class PPO:
         total = T * n
         flat = (self.buf_obs.reshape(total, -1), self.buf_act.reshape(total, 3), self.buf_logp.reshape(total),
                 self.adv.reshape(total), self.ret.reshape(total))
-        bs = min(cfg.batch_size, total)
+        bs = self._bs
         keys = ("pg_loss", "v_loss", "entropy", "clip_frac", "approx_kl")
         use_graph = cfg.graph_update and self.device.type == "cuda" and self.world == 1 and bs <= (1 << 17)
         acc = torch.zeros(len(keys), dtype=torch.float32, device=self.device)   # summed on the device: no per-batch sync
         n_batches = 0
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(total, device=self.device, generator=self.gen)
-            for s in range(0, total - bs + 1, bs):
+            for s in range(0, self._steps_per_epoch * bs, bs):     # the same count on every rank (agreed in __init__)
                 mb = perm[s:s + bs]
                 if use_graph and self._eager_steps >= 3:      # the first steps run eagerly (allocator / Adam state warm-up)
                     g = self._graphed_step(flat, bs)

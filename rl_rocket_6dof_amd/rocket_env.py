@@ -84,7 +84,7 @@ class Simulator6DOF:
         with torch.cuda.device(self.device):
             rc = self.lib.r6_sim_step(C.byref(self._p), _ptr(self._state), _ptr(self._epconst), _ptr(self._u),
                                       _ptr(self._status), 1, self._ld, self._stream())
-        _lib.check(rc, "r6_sim_step")
+        _lib.check(rc, "r6_sim_step", self.lib)
         self.state = self._state[:, 0].cpu().numpy().astype(np.float64)
         status = int(self._status.item())
         self.t = round(self.t + self.timestep, 3)                  # simulator.py:92
@@ -100,7 +100,7 @@ class Simulator6DOF:
         with torch.cuda.device(self.device):
             rc = self.lib.r6_rhs(C.byref(self._p), _ptr(self._state), _ptr(self._epconst), _ptr(self._u),
                                  _ptr(self._dy), 1, self._ld, self._stream())
-        _lib.check(rc, "r6_rhs")
+        _lib.check(rc, "r6_rhs", self.lib)
         return self._dy[:, 0].cpu().numpy().astype(np.float64)
 
     def get_thrust_vector_inertial(self):

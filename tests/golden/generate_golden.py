@@ -25,6 +25,10 @@ What each file pins (reference file:line):
                    the Box like SB3's predict.  The checkpoint tensors are read with
                    torch.load(weights_only=True) -- no pickled code is executed -- and stored in the fixture
                    (they are the reference's data files, 10 k floats each)   (--only g8)
+  g10_velocity_shaping   the reference env with reward_shaping_type='velocity' (rocket_env.py:345-350, :646-674:
+                   _compute_vtarg, two waypoints on either side of the flight, v0 = |IC velocity| recorded):
+                   random-action episodes from the config's IC distribution plus low-altitude ones that end
+                   in ground events   (--only g10)
   g9_shipped_policy_in_reference   the policy trained on the HIP env (examples/policies/) flown in the REFERENCE
                    env: 16 episodes, terminal states, landing flags   (--only g9)
 """
@@ -116,12 +120,12 @@ def _run_episode(env, spy, actions, ic=None, max_steps=None):
                 post=np.array(env.SIM.state, dtype=np.float64),
                 obs=np.asarray(obs, dtype=np.float32),
                 reward=float(rew),
-                terms=np.array([float(rd[t]) for t in TERMS]),
+                terms=np.array([float(rd[t] if t in rd else rd["vtarg_tracking"]) for t in TERMS]),   # slot 0: a|v tracking
                 done=bool(done),
                 bounds=bool(info["bounds_violation"]),
                 status=int(spy.last.status),
                 nfev=int(spy.last.nfev),
-                atarg=np.array(env.get_atarg(), dtype=np.float64),
+                atarg=np.array(env.atarg_history[-1] if env.atarg_history else env.vtarg_history[-1], dtype=np.float64),
                 t=float(env.SIM.t),
                 step=k,
             )
@@ -300,7 +304,65 @@ def gen_g9():
                         ic=np.array(ics), n_steps=np.array(n_steps), terminal=t, ret=np.array(returns), landed=np.array(landed))
 
 
+def gen_g10():
+    """Rocket6DOF with reward_shaping_type == 'velocity' (rocket_env.py:345-350, :646-674)."""
+    import copy
+
+    Sim, Env, cfg = load_reference()
+    sim_module = sys.modules["my_environment.utils.simulator"]
+    spy = _IvpSpy(sim_module)
+    out = {}
+    cfgs = {}
+    for tag, waypoint in (("wp50", 50.0), ("wp400", 400.0)):
+        vcfg = copy.deepcopy(cfg)
+        vcfg["reward_shaping_type"] = "velocity"
+        vcfg["landing_params"]["waypoint"] = waypoint
+        cfgs[tag] = vcfg
+        env = Env(**vcfg)
+        rng = np.random.RandomState(1000 + int(waypoint))
+        eps, x0s, v0s = [], [], []
+        for k in range(4):       # whole flights from the config's IC distribution (both branches of the waypoint test)
+            acts = rng.uniform(-1, 1, (1000, 3)).astype(np.float32)
+            if k >= 2:
+                acts = (0.3 * acts + np.array([0.0, 0.0, 0.1 * k])).astype(np.float32)
+            x0, recs = _run_episode(env, spy, acts, max_steps=150 if k < 2 else None)
+            v0 = float(np.linalg.norm(np.asarray(env.SIM.states[0])[3:6]))     # rocket_env.py:649-651
+            for r in recs:
+                r["v0"] = v0
+            eps.append(recs)
+            x0s.append(x0)
+        for k in range(24):      # low-altitude descents: ground events, goal / final-velocity terms, x around the waypoint
+            icv = np.zeros(14)
+            icv[0] = rng.uniform(0.5, 1.6 * waypoint if k % 2 else 30.0)
+            icv[1:3] = rng.uniform(-60, 60, 2)
+            icv[3] = rng.uniform(-45, -2)
+            icv[4:6] = rng.uniform(-10, 10, 2)
+            icv[6:10] = _quat_from_axis_angle([0.0, rng.normal(), rng.normal() + 1e-9], rng.uniform(0, 0.5))
+            icv[10:13] = rng.uniform(-0.3, 0.3, 3)
+            icv[13] = rng.uniform(30e3, 41.5e3)
+            acts = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+            x0, recs = _run_episode(env, spy, acts, ic=icv)
+            v0 = float(np.linalg.norm(np.asarray(env.SIM.states[0])[3:6]))
+            for r in recs:
+                r["v0"] = v0
+            eps.append(recs)
+            x0s.append(x0)
+        g = _pack(eps)
+        g["v0"] = np.array([r["v0"] for ep in eps for r in ep])
+        g["x0"] = np.array(x0s)
+        for k_, v in g.items():
+            out[f"{tag}_{k_}"] = v
+        print("G10", tag, "steps", len(g["reward"]), "ground events", int((g["status"] == 1).sum()), "done", int(g["done"].sum()),
+              "x>waypoint", int((g["post"][:, 0] > waypoint).sum()))
+    np.savez_compressed(os.path.join(HERE, "g10_velocity_shaping.npz"), config_wp50=np.array(json.dumps(cfgs["wp50"])),
+                        config_wp400=np.array(json.dumps(cfgs["wp400"])),
+                        meta=_meta({"reward_terms": ["vtarg_tracking"] + TERMS[1:]}), **out)
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g10":
+        gen_g10()
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g9":
         gen_g9()
         return

@@ -265,6 +265,30 @@ def test_velocity_shaping_vs_oracle(torch_cuda, cfg):
         assert_close_scaled(terms[i], o["terms"], TERM_SCALE, RTOL, f"velocity shaping terms {i}")
 
 
+@pytest.mark.parametrize("tag", ["wp50", "wp400"])
+@pytest.mark.parametrize("integ", ["rk4", "rk45"])
+def test_g10_velocity_shaping_vs_reference(torch_cuda, tag, integ):
+    """reward_shaping_type == 'velocity' (rocket_env.py:345-350, :646-674: _compute_vtarg) -- the HIP path against
+    the REFERENCE's own run (golden G10: two waypoints, whole flights + ground events, v0 = |IC velocity|)."""
+    torch = torch_cuda
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    G = load_golden("g10_velocity_shaping.npz")
+    vcfg = json.loads(str(G[f"config_{tag}"]))
+    Pv = onp.OracleParams.from_config(vcfg)
+    g = {k[len(tag) + 1:]: G[k] for k in G.files if k.startswith(tag + "_")}
+    n = len(g["reward"])
+    env = BatchedRocket6DOF(n, vcfg, auto_reset=False, record_terms=True, integrator=integ)
+    assert env.term_names[0] == "vtarg_tracking"
+    env.set_state(g["pre"].astype(np.float32), m0=g["m0"].astype(np.float32), v0=g["v0"].astype(np.float32))
+    obs, rew, done, infos = env.step(torch.as_tensor(g["action"], device=env.device))
+    torch.cuda.synchronize()
+    e = _check_against_golden(env, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), g, Pv, f"G10 {tag} {integ}")
+    assert e[0] < 2e-6 and e[2] < RTOL
+    assert "vtarg_tracking" in infos[0]["rewards_dict"]
+
+
 def test_reset_matches_oracle_stream(torch_cuda, cfg, P):
     """Rocket6DOF.reset (rocket_env.py:180-199): the Philox initial-condition stream is bit-identical
     to the oracle's for the 10 plain components; the quaternion (normalised in fp32) to 1 ulp."""
@@ -352,6 +376,68 @@ def test_wrapped_variant_timelimit_clip_removemass(torch_cuda, cfg):
     assert stats["episodes"] >= n and stats["length_sum"] == T * n
     assert abs(stats["return_sum"] - float(ret.sum())) < 1e-3 * max(1.0, abs(float(ret.sum())))
     assert stats["truncated"] + stats["ground"] + stats["bounds"] >= stats["episodes"]
+
+
+def test_wrapped_variant_vs_c_oracle(torch_cuda, cfg):
+    """The fused make_env() stack (main_6DOF.py:33-53, wrappers.py:119-126: RemoveMassFromObs, ClipReward(-1,100),
+    TimeLimit, Monitor, auto-reset) against the ORACLE's independent C restatement of the same stack, teacher-forced
+    step by step: reward, done, TimeLimit.truncated, running and final episode return / length, the 13-wide
+    observation (fresh one for the envs that were reset), the terminal observation."""
+    torch = torch_cuda
+    from oracle import oracle_c as oc
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n, T, seed = 768, 48, 7
+    P = onp.OracleParams.from_config(cfg)
+    env = BatchedRocket6DOF(n, cfg, remove_mass=True, clip_reward=(-1, 100), max_episode_steps=T, seed=seed)
+    ref = oc.BatchOracle(n, cfg, seed=seed, track=True, auto_reset=True, clip_reward=(-1, 100), max_episode_steps=T)
+    env.reset()
+    # low-altitude, fast states for a part of the batch so that ground events / bounds / goal terms occur well before T
+    G4 = load_golden("g4_ground_events.npz")
+    st = env.get_state().cpu().numpy()
+    k4 = min(n // 2, len(G4["pre"]))
+    st[:k4] = G4["pre"][:k4].astype(np.float32)
+    env.set_state(st)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    n_done = n_trunc = n_clip = 0
+    worst_obs = worst_rew = 0.0
+    for k in range(T + 8):
+        a = (torch.rand((n, 3), generator=g) * 2 - 1)
+        # teacher forcing: the oracle starts every step from the HIP path's pre-step state and counters
+        ref.state[:] = env.get_state().cpu().numpy().astype(np.float64)
+        ref.epconst[:, 0] = env.epconst[0, :n].cpu().numpy()
+        ref.epconst[:, 1] = env.epconst[1, :n].cpu().numpy()
+        ref.ep_step[:] = env.ep_step.cpu().numpy().astype(np.uint32)
+        ref.ep_return[:] = env.ep_return.cpu().numpy().astype(np.float64)
+        ref.step_count = env._step_count
+        obs, rew, done, infos = env.step(a.to(env.device))
+        ro, rr, rd = ref.step(a.numpy())
+        d = done.cpu().numpy()
+        np.testing.assert_array_equal(d.astype(np.uint8), rd, err_msg=f"step {k}: done")
+        fl = env.flags.cpu().numpy()
+        np.testing.assert_array_equal(fl, ref.flags, err_msg=f"step {k}: ground / bounds / truncated flags")
+        worst_rew = max(worst_rew, assert_close_scaled(rew.cpu().numpy(), rr, REWARD_SCALE, RTOL, f"step {k}: clipped reward"))
+        assert float(rew.min()) >= -1.0 and float(rew.max()) <= 100.0
+        n_clip += int(((rr == -1.0) | (rr == 100.0)).sum())
+        worst_obs = max(worst_obs, assert_close_scaled(obs.cpu().numpy(), ro[:, :13], 1.0, RTOL, f"step {k}: obs (13-wide, reset envs included)"))
+        # running counters of the live envs, Monitor's episode record and the terminal observation of the finished ones
+        np.testing.assert_array_equal(env.ep_step.cpu().numpy(), ref.ep_step.astype(np.int32))
+        assert_close_scaled(env.ep_return.cpu().numpy(), ref.ep_return, 1.0, RTOL, f"step {k}: running return")
+        if d.any():
+            idx = np.nonzero(d)[0]
+            np.testing.assert_array_equal(env.fin_length.cpu().numpy()[idx], ref.fin_length[idx].astype(np.int32))
+            assert_close_scaled(env.fin_return.cpu().numpy()[idx], ref.fin_return[idx], 1.0, RTOL, f"step {k}: episode return")
+            assert_close_scaled(env.final_obs.cpu().numpy()[idx], ref.final_obs[idx, :13], 1.0, RTOL, f"step {k}: terminal obs")
+            i = int(idx[0])
+            info = infos[i]
+            assert info["episode"]["l"] == int(ref.fin_length[i]) and info["TimeLimit.truncated"] == bool(ref.flags[i] & 4)
+            np.testing.assert_allclose(info["terminal_observation"], ref.final_obs[i, :13], rtol=0, atol=2e-5)
+        n_done += int(d.sum())
+        n_trunc += int(((fl & 4) != 0).sum())
+    print(f"[wrapped vs C oracle] {T + 8} steps x {n} envs: episodes {n_done}, truncated {n_trunc}, clipped rewards {n_clip}, "
+          f"worst obs err {worst_obs:.2e}, reward err {worst_rew:.2e}")
+    assert n_done > n and n_trunc > n // 4 and n_clip > 0
 
 
 def test_single_env_surface(torch_cuda, cfg):

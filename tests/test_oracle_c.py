@@ -139,3 +139,22 @@ def test_quartic_t_go_against_np_roots_on_wide_ranges(cfg, P):
             n_pair += int(any(z.imag > 0 and z.real > 0 for z in roots))
     assert n_pair > 100, "the sample must contain quartics with a complex pair right of the root"
     assert worst < 5e-6, f"tracking term differs from the np.roots restatement: {worst:.3e}"
+
+
+@pytest.mark.parametrize("tag", ["wp50", "wp400"])
+def test_g10_velocity_shaping_vs_reference(tag):
+    """The C restatement with reward_shaping_type == 'velocity' against the reference's own run (golden G10)."""
+    G = load_golden("g10_velocity_shaping.npz")
+    vcfg = json.loads(str(G[f"config_{tag}"]))
+    Pv = onp.OracleParams.from_config(vcfg)
+    g = {k[len(tag) + 1:]: G[k] for k in G.files if k.startswith(tag + "_")}
+    n = len(g["reward"])
+    env = oc.BatchOracle(n, vcfg)
+    env.set_state(g["pre"], m0=g["m0"], v0=g["v0"])
+    obs, rew, done = env.step(g["action"])
+    np.testing.assert_array_equal(done, g["done"])
+    np.testing.assert_array_equal((env.flags & 2) >> 1, g["bounds"])
+    np.testing.assert_array_equal(env.flags & 1, (g["status"] == 1).astype(np.uint8))
+    assert_close_scaled(env.state, g["post"], Pv.normalizer[None, :], 2e-6, "C post-state vs reference (G10)")
+    assert_close_scaled(env.terms, g["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference (G10)")
+    assert_close_scaled(rew, g["reward"], 1e-1, 2e-5, "C reward vs reference (G10)")

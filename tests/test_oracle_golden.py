@@ -204,3 +204,27 @@ def test_g7_reward_wrappers(P):
             n_v += t8[7] != 0
         if "vertical_attitude" in kw:
             assert n_v > 10
+
+
+@pytest.mark.parametrize("tag", ["wp50", "wp400"])
+def test_g10_velocity_shaping(tag):
+    """reward_shaping_type == 'velocity' (rocket_env.py:345-350, :646-674) recorded from the reference itself:
+    the oracle's adaptive flavour to round-off, its fixed-RK4 flavour to the integrator contract."""
+    import json
+
+    from conftest import load_golden
+
+    G = load_golden("g10_velocity_shaping.npz")
+    Pv = onp.OracleParams.from_config(json.loads(str(G[f"config_{tag}"])))
+    g = {k[len(tag) + 1:]: G[k] for k in G.files if k.startswith(tag + "_")}
+    n = len(g["reward"])
+    assert n >= 300 and int((g["status"] == 1).sum()) >= 10
+    wp = Pv.waypoint
+    assert (g["post"][:, 0] > wp).any() and (g["post"][:, 0] <= wp).any()      # both branches of :655
+    for integ, rs, rr, stride in (("adaptive", 2e-8, 5e-6, 4), ("rk4", 2e-6, 2e-5, 1)):
+        for i in range(0, n, stride):
+            out = onp.env_step(g["pre"][i], float(g["m0"][i]), g["action"][i], Pv, integ, 1, v0=float(g["v0"][i]))
+            assert out["done"] == bool(g["done"][i]) and out["bounds"] == bool(g["bounds"][i]) and out["status"] == int(g["status"][i])
+            assert_close_scaled(out["post"], g["post"][i], _scale(Pv), rs, f"G10 {tag} {integ} post {i}")
+            assert_close_scaled(out["terms"], g["terms"][i], 1e-2, rr, f"G10 {tag} {integ} terms {i}")
+            assert_close_scaled(out["reward"], g["reward"][i], 1e-1, rr, f"G10 {tag} {integ} reward {i}")

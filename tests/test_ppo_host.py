@@ -127,15 +127,15 @@ def _free_port():
     return p
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, counts=(64, 64), batch_size=256):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from test_ppo_host import ToyEnv
 
-    env = ToyEnv(64, T=10, seed=100 + rank)          # different data per rank
-    algo = PPO(env, PPOConfig(n_steps=20, batch_size=256, n_epochs=2, seed=5))
+    env = ToyEnv(counts[rank], T=10, seed=100 + rank)          # different data per rank
+    algo = PPO(env, PPOConfig(n_steps=20, batch_size=batch_size, n_epochs=2, seed=5))
     for _ in range(3):
         algo.collect_rollouts()
         algo.train()
@@ -158,6 +158,35 @@ def test_two_rank_gradient_averaging_keeps_replicas_identical():
         assert p.exitcode == 0
     np.testing.assert_array_equal(res[0][1], res[1][1])     # same init + averaged grads => same weights
     assert res[0][2] == 3 * 20 * 64 * 2                     # timesteps count the whole job
+
+
+def test_two_rank_ragged_shards_do_not_hang_and_count_the_whole_job():
+    """dist.shard_range hands out counts that differ by one.  26 vs 25 envs x 20 steps = 520 vs 500 samples with
+    minibatches of 260: rank 0 could run 2 steps per epoch, rank 1 only 1 -- the step count (= number of gradient
+    all-reduces) must be agreed or the job hangs; gradients are weighted by sample share; timesteps are global."""
+    from rl_rocket_6dof_amd.dist import shard_range
+
+    counts = tuple(shard_range(51, r, 2)[1] for r in range(2))
+    assert counts == (26, 25)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q, counts, 260)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] == 3 * 20 * 51
+
+
+def test_ppo_refuses_a_time_limited_env_without_truncation_flags():
+    env = ToyEnv(8, T=5)
+    env.flags = None
+    with pytest.raises(ValueError, match="record_flags"):
+        PPO(env, PPOConfig(n_steps=4, batch_size=16))
 
 
 def test_sb3_checkpoint_tensors_map_onto_both_topologies():
