@@ -9,21 +9,29 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 environments PER GPU (weak scaling: configs[3] = 8 x 2^20 sharded, no collective in step), fixed-step
 RK4, fp32, config.yaml parameters (dt = 0.1 s), i.i.d. U(-1,1) actions pre-generated on the device
 (two buffers used alternately, like a policy's output buffer; generation is outside the timed region), in-kernel auto-reset ON
-so every env is live on every step.  A "step" is one r6_step launch over the rank's shard.  Inputs
-are resident in HBM when the timed region starts.
+so every env is live on every step.  A "step" is one r6_step launch over the rank's shard (with --k K > 1: one of
+the K env steps of an r6_step_k launch).  Inputs are resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / mean launch
 duration measured with HIP events on the launch stream; algorithmic bytes = 189 B/env-step for the raw
 env (read state 56 + m0 4 + action 12; write state 56 + obs 56 + reward 4 + done 1).
-`cpu_baseline` = the reference-equivalent CPU restatement (oracle/, scalar Python: adaptive RK45 +
-ground event + np.roots reward, the same algorithm and structure as the reference's Rocket6DOF.step)
-timed on this box, rank 0, N = 1 only.
+Beside the headline the same line carries (N = 1 only, all timed in this run):
+  `out_of_cache`  the same kernel on 2^23 envs with 8 cold action buffers: a 1.6 GB working set, far beyond the 256 MB
+                  Infinity Cache that holds the whole headline working set (198 MB);
+  `configs1`      BASELINE configs[1] -- 65 536 envs, Euler dt 0.04 -- one launch per step and 16 steps per launch
+                  (r6_step_k), each with its own algorithmic-bytes figure;
+  `cpu_baseline`  the reference-equivalent CPU restatement (oracle/, scalar Python: adaptive RK45 + ground event +
+                  np.roots reward, the same algorithm and structure as the reference's Rocket6DOF.step) on this box.
+With N > 1 the line carries `rccl`: the process-group facts (backend, ranks), per-rank kernel times, and a second short
+timed loop that includes the design's one collective -- the all-gather of episode summaries -- every 32 steps
+(BASELINE configs[4]'s per-rollout exchange).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +42,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_RAW = 189
 BYTES_WRAPPED = 201            # obs 13 floats (-4 B), ep_step r+w (+8), ep_return r+w (+8)
+TRAFFIC_PROFILE = os.path.join("profiles", "r2_pmc_traffic.json")
+
+
+def bytes_per_env_step(variant: str, k: int = 1, obs_dim: int = 14) -> float:
+    """Algorithmic bytes per env-step.  One launch per step: SURVEY 8(d).  K steps per launch (r6_step_k): the action
+    read and the per-step outputs (obs, reward, done) stay, the state / m0 / v0 (and episode counter) traffic is paid
+    once per K steps."""
+    if k <= 1:
+        return float(BYTES_WRAPPED if variant == "wrapped" else BYTES_RAW)
+    per_step = 12 + 4 * obs_dim + 4 + 1
+    once = 56 + 56 + 2 * 8 + (16 if variant == "wrapped" else 0)      # state r+w, epconst rows r+w, ep_step / ep_return r+w
+    return per_step + once / k
 
 
 def cpu_baseline(seconds: float):
@@ -80,7 +100,7 @@ def cpu_baseline_c(seconds: float):
         return {"error": repr(e)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -90,6 +110,9 @@ def main():
     ap.add_argument("--dt", type=float, default=None, help="env timestep (default: config.yaml 0.1)")
     ap.add_argument("--variant", default="raw", choices=["raw", "wrapped"],
                     help="raw = Rocket6DOF.step (189 B); wrapped = fused make_env() stack (201 B)")
+    ap.add_argument("--k", type=int, default=1,
+                    help="env steps per kernel launch (r6_step_k; 1 = one r6_step launch per step, the headline). --steps "
+                         "still counts env steps and must be a multiple of k")
     ap.add_argument("--pool", type=int, default=2,
                     help="number of pre-generated action buffers cycled through.  In use the action tensor is what the "
                          "policy wrote a moment ago, i.e. resident in the 256 MB Infinity Cache when the step reads it; "
@@ -101,7 +124,136 @@ def main():
                          "steady mix of flight phases")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the out_of_cache / configs1 side measurements (N = 1)")
+    ap.add_argument("--gather-every", type=int, default=32,
+                    help="N > 1: period (steps) of the episode-summary all-gather in the second timed loop")
+    return ap.parse_args(argv)
+
+
+def git_commit() -> str:
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip() or "unknown"
+    except Exception:
+        return "unknown"
+
+
+def traffic_from_profile(variant: str, integrator: str, n: int, k: int):
+    """HBM bytes per launch from the committed PMC profile of THIS workload (separate --pmc passes, scripts/
+    profile_round.sh).  It is a file constant, not measured in this run: `traffic_source` says so."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    if not (os.path.exists(path) and variant == "raw" and integrator == "rk4" and n == (1 << 20) and k == 1):
+        return None, None
+    try:
+        prof = json.load(open(path))
+        return prof.get("hbm_bytes_per_launch"), f"{TRAFFIC_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')})"
+    except Exception:
+        return None, None
+
+
+def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: float, *, traffic=None, traffic_source=None,
+               extras=None) -> dict:
+    """The ONE JSON line of the bench contract from the reduced measurements (pure function: testable without a GPU).
+    wall = seconds of the timed region (max over ranks); kernel_ms = mean milliseconds per env step on the launch
+    stream (max over ranks)."""
+    total = n * world
+    bytes_per = bytes_per_env_step(args.variant, args.k, 13 if args.variant == "wrapped" else 14)
+    achieved = bytes_per * n / (kernel_ms * 1e-3) / 1e9
+    kernel = "r6::step_kernel" if args.k <= 1 else f"r6::step_k_kernel (K={args.k})"
+    line = {
+        "metric": "env-steps/sec at N=2^20 envs per MI355X",
+        "value": total * args.steps / wall,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{n} envs/GPU x {world} GPU, {args.integrator} dt={dt} fp32, {args.variant} "
+                               f"Rocket6DOF.step, random actions, auto-reset, {args.burnin} burn-in steps, "
+                               f"{args.k} env step(s) per launch",
+                   "envs_total": total, "integrator": args.integrator, "dt": dt, "variant": args.variant,
+                   "steps_per_launch": args.k, "bytes_per_env_step": bytes_per, "parallelism": f"env-shard x{world}",
+                   "commit": git_commit()},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_us": kernel_ms * 1e3 * max(args.k, 1), "kernel": kernel,
+                     "working_set_note": "189 B x 2^20 = 198 MB per launch fits the 256 MB Infinity Cache: see out_of_cache "
+                                         "for the same kernel against HBM proper" if n * bytes_per < 256e6 else None},
+    }
+    if extras:
+        line.update(extras)
+    return line
+
+
+def timed_loop(env, pool, steps: int, k: int, barrier, stream, torch, every=None):
+    """Times `steps` env steps (launches of k steps each) between two barriers; returns (wall seconds, ms per env step
+    on the launch stream).  `every` = (period, fn): fn() is called after each `period` steps inside the timed region."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    npool = len(pool)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    if k <= 1:
+        for j in range(steps):
+            env.step_async(pool[j % npool])
+            if every is not None and (j + 1) % every[0] == 0:
+                every[1]()
+    else:
+        for j in range(steps // k):
+            env.step_k(pool[j % npool], out=env._bench_out)
+            if every is not None and ((j + 1) * k) % every[0] == 0:
+                every[1]()
+    ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, ev0.elapsed_time(ev1) / steps
+
+
+def make_pool(torch, n, k, count, dev, seed):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    shape = (n, 3) if k <= 1 else (k, n, 3)
+    return [(torch.rand(shape, generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(count)]
+
+
+def side_measurement(torch, dev, cfg, *, n, integrator, dt, k, pool_count, burnin, steps, warmup, label):
+    """One secondary workload timed in the same run (N = 1): returns a dict with its own algorithmic-bytes figure."""
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    env = BatchedRocket6DOF(n, cfg, device=dev, integrator=integrator, timestep=dt, auto_reset=True, record_flags=False,
+                            record_terms=False, track_episodes=False, seed=42)
+    pool = make_pool(torch, n, k, pool_count, dev, 4321)
+    env.reset()
+    if k <= 1:
+        for j in range(burnin):
+            env.step_async(pool[j % pool_count])
+    else:
+        for j in range(max(1, burnin // k)):
+            env.step_k(pool[j % pool_count], last_only=True)
+        env._bench_out = env.step_k(pool[0])
+    sync = lambda: torch.cuda.synchronize(dev)
+    stream = torch.cuda.current_stream(dev)
+    timed_loop(env, pool, warmup, k, sync, stream, torch)
+    wall, ms = timed_loop(env, pool, steps, k, sync, stream, torch)
+    bpe = bytes_per_env_step("raw", k)
+    ach = bpe * n / (ms * 1e-3) / 1e9
+    out = {"workload": label, "envs": n, "integrator": integrator, "dt": dt or cfg["timestep"], "steps_per_launch": k,
+           "steps": steps, "action_buffers": pool_count, "value": n * steps / wall, "unit": "env-steps/s",
+           "us_per_env_step": ms * 1e3, "bytes_per_env_step": bpe, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+           "working_set_MB": bpe * n / 1e6}
+    del env, pool
+    torch.cuda.empty_cache()
+    return out
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.k > 1 and args.steps % args.k:
+        raise SystemExit("--steps must be a multiple of --k")
 
     import torch
     import torch.distributed as dist
@@ -119,89 +271,78 @@ def main():
     local = int(os.environ.get("R6_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    on_gpu_pg = world > 1 and dist.get_backend() == "nccl"
+    backend = dist.get_backend() if world > 1 else None
+    on_gpu_pg = backend == "nccl"
 
     n = args.envs_per_gpu
-    total = n * world
     cfg = default_env_config()
     wrapped = args.variant == "wrapped"
-    offset = rank * n
+    multi = world > 1
     env = BatchedRocket6DOF(
-        n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=offset, auto_reset=True,
-        record_flags=False, record_terms=False, track_episodes=wrapped,
+        n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=rank * n, auto_reset=True,
+        record_flags=False, record_terms=False, track_episodes=wrapped or multi,
         remove_mass=wrapped, clip_reward=(-1, 100) if wrapped else None,
         max_episode_steps=int(150 / (args.dt or cfg["timestep"])) if wrapped else 0, seed=42)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = [(torch.rand((n, 3), generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(args.pool)]
+    pool = make_pool(torch, n, args.k, args.pool, dev, 1234 + rank)
     env.reset()
-    for k in range(args.burnin):
-        env.step_async(pool[k % args.pool])
+    if args.k <= 1:
+        for j in range(args.burnin):
+            env.step_async(pool[j % args.pool])
+    else:
+        for j in range(max(1, args.burnin // args.k)):
+            env.step_k(pool[j % args.pool], last_only=True)
+        env._bench_out = env.step_k(pool[0])
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        env.step_async(pool[k % args.pool])
-    barrier()
-
     stream = torch.cuda.current_stream(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(args.steps):
-        env.step_async(pool[k % args.pool])
-    ev1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # mean launch-to-launch duration on the stream
+    timed_loop(env, pool, max(args.warmup, args.k), args.k, barrier, stream, torch)        # W untimed steps
+    wall, kernel_ms = timed_loop(env, pool, args.steps, args.k, barrier, stream, torch)    # EXACTLY K timed steps
 
-    if world > 1:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev if on_gpu_pg else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(t[0]), float(t[1])
-        # the one collective of the design (episode summaries), exercised outside the timed region
-        if env.stats is not None:
-            r6dist.gather_episode_stats(env.episode_stats(), device=dev)
+    extras = {}
+    if multi:
+        red = r6dist.reduce_bench_times(wall, kernel_ms, device=dev)
+        wall, kernel_ms = red["wall_max"], red["kernel_ms_max"]
+        # the one collective of the design (episode summaries) inside a second, short timed loop:
+        # BASELINE configs[4]'s per-rollout exchange
+        gsteps = max(args.gather_every, min(args.steps, 10 * args.gather_every) // args.gather_every * args.gather_every)
+        gathers = []
+        wall_g, _ = timed_loop(env, pool, gsteps, args.k, barrier, stream, torch,
+                               every=(args.gather_every, lambda: gathers.append(r6dist.gather_episode_stats(env.episode_stats(), device=dev)[0])))
+        redg = r6dist.reduce_bench_times(wall_g, 0.0, device=dev)
+        extras["rccl"] = {"backend": backend, "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
+                          "kernel_us_min": red["kernel_ms_min"] * 1e3, "kernel_us_max": red["kernel_ms_max"] * 1e3,
+                          "wall_s_min": red["wall_min"], "wall_s_max": red["wall_max"],
+                          "with_rollout_gather": {"gather_every": args.gather_every, "steps": gsteps, "gathers": len(gathers),
+                                                  "value": n * world * gsteps / redg["wall_max"], "unit": "env-steps/s",
+                                                  "episodes_seen": gathers[-1]["episodes"] if gathers else 0.0}}
 
     if rank == 0:
-        bytes_per = BYTES_WRAPPED if wrapped else BYTES_RAW
-        achieved = bytes_per * n / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if os.path.exists(tpath) and not wrapped and args.integrator == "rk4" and n == (1 << 20):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         dt = args.dt or cfg["timestep"]
-        line = {
-            "metric": "env-steps/sec at N=2^20 envs per MI355X",
-            "value": total * args.steps / wall,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{n} envs/GPU x {world} GPU, {args.integrator} dt={dt} fp32, {args.variant} "
-                                   f"Rocket6DOF.step, random actions, auto-reset, {args.burnin} burn-in steps",
-                       "envs_total": total, "integrator": args.integrator, "dt": dt, "variant": args.variant,
-                       "bytes_per_env_step": bytes_per, "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_us": kernel_ms * 1e3, "kernel": "r6::step_kernel"},
-        }
-        if world == 1 and not args.no_cpu_baseline and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        traffic, source = traffic_from_profile(args.variant, args.integrator, n, args.k)
+        if not multi and not args.no_extras:
+            del env, pool
+            torch.cuda.empty_cache()
+            extras["out_of_cache"] = side_measurement(
+                torch, dev, cfg, n=1 << 23, integrator="rk4", dt=None, k=1, pool_count=8, burnin=600, steps=200, warmup=40,
+                label="2^23 envs, RK4 dt 0.1, raw step, 8 cold action buffers: same kernel, 1.6 GB working set (HBM, not the Infinity Cache)")
+            extras["configs1"] = {
+                "one_launch_per_step": side_measurement(
+                    torch, dev, cfg, n=65536, integrator="euler", dt=0.04, k=1, pool_count=2, burnin=2000, steps=4000,
+                    warmup=400, label="BASELINE configs[1]: 65 536 envs, Euler dt 0.04, r6_step per step"),
+                "k16": side_measurement(
+                    torch, dev, cfg, n=65536, integrator="euler", dt=0.04, k=16, pool_count=2, burnin=2000, steps=8000,
+                    warmup=800, label="BASELINE configs[1]: 65 536 envs, Euler dt 0.04, r6_step_k with 16 steps per launch, "
+                                      "all per-step outputs stored")}
+        if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:
+            extras["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        line = build_line(args, world, n, dt, wall, kernel_ms, traffic=traffic, traffic_source=source, extras=extras)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

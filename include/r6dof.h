@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define R6_ABI_VERSION 3
+#define R6_ABI_VERSION 4
 #define R6_STATE_DIM 14
 #define R6_ACTION_DIM 3
 #define R6_NUM_TERMS 8 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
@@ -133,7 +133,7 @@ typedef struct R6Buffers {
     float *fin_return;    /* [n]       out at done: episode return */
     uint32_t *fin_length; /* [n]       out at done: episode length */
     uint8_t *nfev;        /* [n]       out: RHS evaluations of the step (scipy sol.nfev), saturating at 255 */
-    float *stats;         /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out: per-workgroup running sums over
+    double *stats;        /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out (float64: counts stay exact): per-workgroup running sums over
                                        finished episodes (see R6_STAT_*): accumulated with LDS float
                                        atomics inside a workgroup, then added to the workgroup's own row
                                        (no global atomics); the caller sums the rows */
@@ -151,6 +151,34 @@ const char *r6_last_error(void);
  * this shard's env 0) key the counter-based reset RNG, so results do not depend on sharding. */
 int r6_step(const R6Params *params, const R6Buffers *buf, uint64_t seed, uint64_t step_index,
             uint64_t env_offset, void *stream);
+
+/* K consecutive Rocket6DOF.step calls in one launch (the per-timestep loop of main_6DOF.py:136-139 /
+ * montecarlo_script.py:33-51 without its per-step launch): actions for all K steps are given up front (open-loop
+ * rollouts: random or pre-computed action sequences), the state stays in registers between the steps, finished
+ * episodes are re-sampled in-kernel exactly as r6_step does it.  Results are bit for bit those of K r6_step calls with
+ * step_index, step_index + 1, ...
+ * Arrays that r6_step produces per step carry a leading K dimension here, addressed with the element strides below
+ * (stride 0: all steps write the same buffer, as K r6_step calls on one R6Buffers would):
+ *   action (k,n,3) in;  obs (k,n,obs_dim), reward (k,n), done (k,n), flags (k,n), nfev (k,n), terms (k,8,ld),
+ *   final_obs (k,n,obs_dim), fin_return / fin_length (k,n) out.
+ * state, epconst, ep_step, ep_return, stats are the same single arrays as in r6_step (read before / written after). */
+enum { R6_K_LAST_ONLY = 1 /* only the last step's per-step outputs are stored (throughput rollouts, burn-in) */ };
+typedef struct R6StepK {
+    int32_t k;                /* env steps in this launch, 1..65536 */
+    int32_t flags;            /* R6_K_* */
+    int64_t action_stride;    /* elements from step j to step j+1 of `action` (n*3 when contiguous) */
+    int64_t obs_stride;       /* ... of `obs` (n*obs_dim) */
+    int64_t reward_stride;    /* ... of `reward` (n) */
+    int64_t done_stride;      /* ... of `done` (n) */
+    int64_t flags_stride;     /* ... of `flags` (n) */
+    int64_t nfev_stride;      /* ... of `nfev` (n) */
+    int64_t terms_stride;     /* ... of `terms` (8*ld) */
+    int64_t final_obs_stride; /* ... of `final_obs` (n*obs_dim) */
+    int64_t fin_stride;       /* ... of `fin_return` and `fin_length` (n) */
+} R6StepK;
+size_t r6_stepk_size(void);    /* sizeof(R6StepK) */
+int r6_step_k(const R6Params *params, const R6Buffers *buf, const R6StepK *steps, uint64_t seed, uint64_t step_index,
+              uint64_t env_offset, void *stream);
 
 /* Rocket6DOF.reset for the envs with mask[i] != 0 (mask == NULL: all), rocket_env.py:180-199:
  * samples the initial condition, normalises the quaternion, sets m0/v0, writes obs, zeroes the

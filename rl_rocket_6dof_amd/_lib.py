@@ -7,12 +7,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .params import R6Buffers, R6Params, R6PolicyNet
+from .params import R6Buffers, R6Params, R6PolicyNet, R6StepK
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIBS = {}
 
-SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_reset",
+SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad")
 
 
@@ -45,6 +45,8 @@ def load(path: str | None = None):
     lib.r6_buffers_size.restype = C.c_size_t
     lib.r6_last_error.restype = C.c_char_p
     lib.r6_step.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), u64, u64, u64, vp]
+    lib.r6_stepk_size.restype = C.c_size_t
+    lib.r6_step_k.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), C.POINTER(R6StepK), u64, u64, u64, vp]
     lib.r6_reset.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), vp, u64, u64, u64, vp]
     lib.r6_observe.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), vp]
     lib.r6_sim_step.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
@@ -53,12 +55,14 @@ def load(path: str | None = None):
     lib.r6_policy_act.argtypes = [C.POINTER(R6PolicyNet), vp, i64, vp, vp, vp, vp, u64, u64, u64, C.c_int, vp]
     f32 = C.c_float
     lib.r6_ppo_loss_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
-    for name in ("r6_step", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):
+    for name in ("r6_step", "r6_step_k", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):
         getattr(lib, name).restype = C.c_int
     if lib.r6_abi_version() != ABI_VERSION:
         raise ImportError(f"libr6dof.so ABI {lib.r6_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     if lib.r6_params_size() != C.sizeof(R6Params) or lib.r6_buffers_size() != C.sizeof(R6Buffers):
         raise ImportError("R6Params/R6Buffers layout mismatch between params.py and libr6dof.so: rebuild")
+    if lib.r6_stepk_size() != C.sizeof(R6StepK):
+        raise ImportError("R6StepK layout mismatch between params.py and libr6dof.so: rebuild")
     if lib.r6_policy_net_size() != C.sizeof(R6PolicyNet):
         raise ImportError("R6PolicyNet layout mismatch between params.py and libr6dof.so: rebuild")
     _LIBS[path] = lib

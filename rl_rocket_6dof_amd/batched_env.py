@@ -24,8 +24,8 @@ import torch
 
 from . import _lib
 from .compat import Box, VecEnv
-from .params import (ACTION_DIM, MAX_BLOCKS, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS, STATE_DIM,
-                     STAT_NAMES, R6Buffers, default_env_config, make_params)
+from .params import (ACTION_DIM, K_LAST_ONLY, MAX_BLOCKS, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS,
+                     STATE_DIM, STAT_NAMES, R6Buffers, R6StepK, default_env_config, make_params)
 
 TERM_NAMES_ACC = ("atarg_tracking", "thrust_penalty", "eta", "attitude_constraint", "goal_conditions",
                   "final_position", "final_velocity",          # rocket_env.py:342-359
@@ -193,7 +193,7 @@ class BatchedRocket6DOF(VecEnv):
         self.ep_return = torch.zeros((n,), **f32) if track else None
         self.fin_return = torch.zeros((n,), **f32) if (track and auto_reset) else None
         self.fin_length = torch.zeros((n,), dtype=torch.int32, device=dev) if (track and auto_reset) else None
-        self.stats = torch.zeros((MAX_BLOCKS, NUM_STATS), **f32) if track else None
+        self.stats = torch.zeros((MAX_BLOCKS, NUM_STATS), dtype=torch.float64, device=dev) if track else None   # float64: counts stay exact
 
         self._buf = R6Buffers()
         self._fill_buffers(self._act)
@@ -270,6 +270,63 @@ class BatchedRocket6DOF(VecEnv):
         self.step_async(actions)
         return self.step_wait()
 
+    def step_k(self, actions, *, last_only: bool = False, out: Optional[dict] = None) -> dict:
+        """K env steps in ONE kernel launch (``r6_step_k``): the per-timestep loop of the reference
+        (main_6DOF.py:136-139, montecarlo_script.py:33-51) for open-loop action sequences -- random-action rollouts,
+        replayed trajectories, burn-in -- without a launch per step.  ``actions``: device tensor (K, N, 3).
+
+        Returns a dict of device tensors with a leading K dimension: ``obs`` (K,N,obs_dim), ``reward`` (K,N), ``done``
+        (K,N) and, when the env records them, ``flags``, ``terms`` (K,8,ld), ``nfev``, ``final_obs`` (K,N,obs_dim; rows of
+        envs that finished in that step), ``fin_return`` / ``fin_length`` (K,N).  Results are bit for bit those of K
+        ``step`` calls.  ``last_only=True`` keeps just the last step's outputs (in the env's own single-step buffers:
+        ``env.obs`` ...) and stores nothing for the earlier ones.  ``out`` recycles a dict returned by an earlier call
+        with the same K."""
+        a = actions
+        if not (torch.is_tensor(a) and a.device == self.device and a.dtype == torch.float32 and a.is_contiguous()
+                and a.dim() == 3 and tuple(a.shape[1:]) == (self.num_envs, ACTION_DIM) and a.data_ptr() % 16 == 0):
+            a = torch.as_tensor(actions, dtype=torch.float32, device=self.device).reshape(-1, self.num_envs, ACTION_DIM).contiguous()
+        K, n, od, dev = int(a.shape[0]), self.num_envs, self.obs_dim, self.device
+        if K < 1:
+            raise ValueError("step_k needs at least one step of actions")
+        sk = R6StepK(k=K, flags=K_LAST_ONLY if last_only else 0, action_stride=n * ACTION_DIM)
+        b = R6Buffers.from_buffer_copy(self._buf)
+        b.action = _ptr(a)
+        if last_only:
+            res = {"obs": self.obs, "reward": self.reward, "done": self.done.view(torch.bool)}
+        else:
+            res = out if out is not None and out["reward"].shape[0] == K else None
+            if res is None:
+                f32 = dict(dtype=torch.float32, device=dev)
+                u8 = dict(dtype=torch.uint8, device=dev)
+                pitch = (n * od + 3) // 4 * 4     # per-step blocks start 16-byte aligned (the kernel stores 16 B per lane)
+                rows = lambda: torch.zeros((K, pitch), **f32)[:, : n * od].view(K, n, od)
+                res = {"obs": rows(), "reward": torch.empty((K, n), **f32), "_done_u8": torch.empty((K, n), **u8)}
+                if self.flags is not None:
+                    res["flags"] = torch.empty((K, n), **u8)
+                if self.terms is not None:
+                    res["terms"] = torch.zeros((K, NUM_TERMS, self.ld), **f32)
+                if self.nfev is not None:
+                    res["nfev"] = torch.empty((K, n), **u8)
+                if self.final_obs is not None:
+                    res["final_obs"] = rows()
+                if self.fin_return is not None:
+                    res["fin_return"] = torch.zeros((K, n), **f32)
+                    res["fin_length"] = torch.zeros((K, n), dtype=torch.int32, device=dev)
+                res["done"] = res["_done_u8"].view(torch.bool)
+            b.obs, b.reward, b.done = _ptr(res["obs"]), _ptr(res["reward"]), _ptr(res["_done_u8"])
+            b.flags, b.terms, b.nfev = _ptr(res.get("flags")), _ptr(res.get("terms")), _ptr(res.get("nfev"))
+            b.final_obs, b.fin_return, b.fin_length = _ptr(res.get("final_obs")), _ptr(res.get("fin_return")), _ptr(res.get("fin_length"))
+            sk.obs_stride, sk.final_obs_stride = res["obs"].stride(0), (res["final_obs"].stride(0) if "final_obs" in res else 0)
+            sk.reward_stride = sk.done_stride = sk.flags_stride = sk.nfev_stride = sk.fin_stride = n
+            sk.terms_stride = NUM_TERMS * self.ld
+        with torch.cuda.device(dev):
+            rc = self.lib.r6_step_k(C.byref(self.params), C.byref(b), C.byref(sk), self._seed, self._step_count + 1,
+                                    self.env_offset, self._stream())
+        _lib.check(rc, "r6_step_k", self.lib)
+        self._step_count += K
+        self._pending = a
+        return res
+
     # ------------------------------------------------------------------------------------------
     def get_state(self) -> torch.Tensor:
         """(N,14) copy of the simulator states (rocket_env.py:623)."""
@@ -316,7 +373,7 @@ class BatchedRocket6DOF(VecEnv):
         float64 on the host)."""
         if self.stats is None:
             raise RuntimeError("episode tracking is disabled (track_episodes=False)")
-        s = self.stats.double().sum(0).cpu().numpy()
+        s = self.stats.sum(0).cpu().numpy()
         if clear:
             self.stats.zero_()
         return {k: float(s[i]) for i, k in enumerate(STAT_NAMES)}

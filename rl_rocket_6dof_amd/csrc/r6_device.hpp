@@ -125,9 +125,15 @@ struct Rot {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
 
+#ifndef R6_OPT_UNITQ
+#define R6_OPT_UNITQ 1   // A/B switch: the reward's rotation matrix skips 1/|q|^2 (the step has just renormalised q)
+#endif
+
+template <bool UNIT = false>
 __device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
-    const float n2 = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, q3 * q3)));
-    const float s = 2.0f * frcp(n2);
+    // UNIT: the caller guarantees |q| = 1 to fp32 round-off (sim:97 renormalises after every step), s = 2 / |q|^2 = 2
+    float s = 2.0f;
+    if constexpr (!UNIT) s = 2.0f * frcp(fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, q3 * q3))));
     const float s1 = s * q1, s2 = s * q2, s3 = s * q3;
     const float w1 = s1 * q0, w2 = s2 * q0, w3 = s3 * q0;
     const float x1 = s1 * q1, x2 = s2 * q1, x3 = s3 * q1;
@@ -243,10 +249,7 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Co
 #ifndef R6_RK4_ROLLED
 #define R6_RK4_ROLLED 0
 #endif
-#ifndef R6_OPT_PK
-#define R6_OPT_PK 0   // A/B switch: slope combination of the RK4 stages as packed fp32 (v_pk_fma_f32)
-#endif
-typedef float pf2 __attribute__((ext_vector_type(2)));
+
 
 // One application of the Euler / RK4 map.
 template <int INTEG>
@@ -264,45 +267,6 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
         // stage masses m, m-h/2 mdot (x2), m-h mdot.
         const float hh = 0.5f * h;
         const float h6 = h * (1.0f / 6.0f);
-#if R6_OPT_PK
-        // The 24 multiply-adds per stage that combine the slopes (12 live components x {accumulate, next argument}) are
-        // pairwise independent: held as float2 they issue as 12 v_pk_fma_f32 (1.3 issue slots per pair instead of 2).
-        constexpr int kPairs = 6;
-        constexpr int kIdx[kPairs][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {11, 12}};   // omega_x (10) is constant
-        pf2 y0p[kPairs], y1p[kPairs];
-        float yt[kDyn];
-#pragma unroll
-        for (int j = 0; j < kPairs; ++j) {
-            y0p[j] = pf2{y0[kIdx[j][0]], y0[kIdx[j][1]]};
-            y1p[j] = y0p[j];
-        }
-#pragma unroll
-        for (int i = 0; i < kDyn; ++i) yt[i] = y0[i];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float tm = (s == 0) ? 0.0f : ((s == 3) ? h : hh);
-            const float w = (s == 0 || s == 3) ? h6 : 2.0f * h6;
-            const float an = (s == 2) ? h : hh;
-            rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, kend);
-            const pf2 wp = pf2{w, w}, anp = pf2{an, an};
-#pragma unroll
-            for (int j = 0; j < kPairs; ++j) {
-                const pf2 kp = pf2{kend[kIdx[j][0]], kend[kIdx[j][1]]};
-                y1p[j] = __builtin_elementwise_fma(wp, kp, y1p[j]);
-                if (s < 3) {
-                    const pf2 a = __builtin_elementwise_fma(anp, kp, y0p[j]);
-                    yt[kIdx[j][0]] = a.x;
-                    yt[kIdx[j][1]] = a.y;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kPairs; ++j) {
-            y1[kIdx[j][0]] = y1p[j].x;
-            y1[kIdx[j][1]] = y1p[j].y;
-        }
-        y1[10] = y0[10];
-#else
         float yt[kDyn];
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) {
@@ -326,7 +290,6 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
                 yt[i] = fmaf(an, kend[i], y0[i]);
             }
         }
-#endif
     }
 }
 
@@ -769,7 +732,7 @@ __device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[
     RewardOut o;
     const float rx = y[0], ry = y[1], rz = y[2];
     const float vx = y[3], vy = y[4], vz = y[5];
-    const Rot R = rotmat(y[6], y[7], y[8], y[9]);
+    const Rot R = rotmat<R6_OPT_UNITQ != 0>(y[6], y[7], y[8], y[9]);   // post-step attitude: renormalised by integrate()
     const float vv = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
     const float rr = fmaf(rx, rx, fmaf(ry, ry, rz * rz));
     const float vn = fsqrt(vv);

@@ -45,6 +45,12 @@ __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) 
 //     SGPRs across the loop.
 // -------------------------------------------------------------------------------------------------
 constexpr int kWaves = kBlock / 64;
+#ifndef R6_PRIO_REMAINING
+#define R6_PRIO_REMAINING 0     // A/B switch: wave priority from the tiles left (1: measured 0.4-1.6 us slower) or from the tiles done (0)
+#endif
+#ifndef R6_WG_DYNAMIC
+#define R6_WG_DYNAMIC 1         // A/B switch (Euler instances): the waves of a workgroup pull the workgroup's tiles from an LDS counter (1) or own fixed lists (0)
+#endif
 #ifndef R6_RESET_QUEUE
 #define R6_RESET_QUEUE 2048
 #endif
@@ -177,7 +183,8 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
-                                                      const uint64_t step_index, const uint64_t env_offset) {
+                                                      const uint64_t step_index, const uint64_t env_offset,
+                                                      const uint32_t even_share_q16) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
     // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     __shared__ float lds_inv_norm[R6_STATE_DIM];
     __shared__ int rq[kResetQueueCap];
     __shared__ int rq_count;
+    __shared__ int wg_next;
     __shared__ float blk_stats[R6_NUM_STATS];
 
     const int tid = threadIdx.x;
@@ -195,15 +203,33 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     float* tile = tiles[wave];
     const int64_t n = b.n;
     const int64_t n_tiles = (n + 63) >> 6;
-    const int64_t nw = (int64_t)gridDim.x * kWaves;
-    const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
+    // XCD-aware tile split.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 = XCC_ID, checked with
+    // s_getreg in the trace build), and the odd XCDs of an MI355X see a ~1 us longer load latency than the even
+    // ones (per-wave stamps, scripts/trace_timeline.py: load wait 3.1 vs 2.0 us per tile, same compute time): with
+    // equal shares the even XCDs are done at 0.8 of the launch.  even_share_q16 > 0 (persistent grids only): the tile
+    // range is cut into an even-XCD pool of n_tiles * share / 65536 tiles and an odd-XCD pool with the rest, each
+    // walked round-robin by the waves of its own workgroups.  0: one pool for everybody.
+    int64_t nw = (int64_t)gridDim.x * kWaves;
+    int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
+    int64_t pool_base = 0, pool_tiles = n_tiles;
+    if (even_share_q16 != 0u) {
+        const int64_t n_even = (n_tiles * (int64_t)even_share_q16) >> 16;
+        const bool odd = (blockIdx.x & 1u) != 0u;
+        pool_base = odd ? n_even : 0;
+        pool_tiles = odd ? n_tiles - n_even : n_even;
+        nw = (int64_t)(gridDim.x >> 1) * kWaves;
+        t_first = (int64_t)(blockIdx.x >> 1) * kWaves + wave;
+    }
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
     const bool opt_flags_terms = b.flags != nullptr || b.terms != nullptr || b.nfev != nullptr;
 
-#ifdef R6_PHASE_TIMING   // dev build: 100 MHz wall-clock stamps per workgroup instead of the episode statistics
+#if defined(R6_PHASE_TIMING) || defined(R6_TRACE)   // dev builds: 100 MHz wall-clock stamps instead of the episode statistics
     const uint64_t pt0 = wall_clock64();
 #endif
-    if (tid == 0) rq_count = 0;
+    if (tid == 0) {
+        rq_count = 0;
+        wg_next = kWaves;   // list entries 0..kWaves-1 are the waves' fixed first tiles
+    }
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
     if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
         const kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -398,28 +424,63 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     // launch runs on the few waves that were starved until then, with nothing left to hide their latencies
     // behind (wall-clock stamps per wave: scripts/phase_timing.py).  Each wave therefore lowers its own
     // priority as it completes tiles: laggards go first, the waves of a SIMD advance together and the tail
-    // shrinks (A/B at N = 2^20: 42.3 -> 40.2 us).  Handing the tiles out dynamically instead (one fetch-add
-    // counter per group of 20 workgroups; a single counter serialises at 11 ns per fetch-add) was measured
-    // too and changes nothing: what is left of the spread in wave end times (~one tile time of 8-10 us) is
-    // the ramp of the first loads -- 5120 waves ask for 30 MB at t = 0 and are served over ~6 us.
+    // shrinks (A/B at N = 2^20: 42.3 -> 40.2 us).  (Priority from the tiles still to do instead of the tiles done, so
+    // that a wave with one tile more runs ahead: 0.4-1.6 us slower.)
+    //
+    // What the per-wave stamps of round 2 show (scripts/trace_timeline.py): first data reaches a
+    // SIMD ~4 us after kernel entry (1 us dispatch + kernarg, 3 us for the 24 MB of first-tile loads); from 6 to
+    // ~28 us 95-100 % of the SIMDs have a wave in its compute phase; then the SIMDs run dry between 30 and 38 us -- the
+    // mean SIMD is done at 0.84 of the launch.  Which SIMD is late changes from launch to launch (no correlation
+    // between launches, workgroups land on different CUs each time); the one systematic part is the XCD parity
+    // handled by the tile split above.  Pulling tiles from shared global counters balances nothing here: device-scope
+    // atomics cross the 8 XCDs' L2s and cost ~140 ns each when 5120 waves use them (840 us per launch, measured);
+    // pulling them from an LDS counter inside a workgroup helps the Euler instances only (see below).
     const int64_t n_full = n >> 6;  // tiles [0, n_full) are full; tile n_full (if any) is partial
     int tile_no = 0;
     constexpr bool kPrefetch = (INTEG == R6_EULER);
     TileIn nxt;
     bool have_nxt = false;
+    // Tile hand-out inside a workgroup (Euler instances).  The four waves of a workgroup sit on the four SIMDs of a
+    // CU, and per-wave stamps (scripts/trace_timeline.py) show the SIMDs of one CU finishing equal tile lists 3 us
+    // apart on average (which one is late changes from launch to launch).  With kWgDyn the workgroup's tiles --
+    // groups of kWaves consecutive tiles, one group per round of the grid -- are claimed through an LDS counter: a
+    // wave that is ahead takes the next tile of its workgroup (claimed one tile ahead, which is what the register
+    // prefetch needs anyway).  The first tile of every wave is fixed.  List index j -> pool tile
+    // (j / kWaves) * nw + first tile of the workgroup + (j % kWaves).  Measured at N = 2^20: Euler 35.1 -> 34.0 us;
+    // the RK4 instances lose with it (38.1 -> 38.7 claimed ahead, 40.0 claimed late: a wave that takes a tile late
+    // in the launch finishes it alone) and keep their fixed per-wave lists.
+    constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;
+    int wg_j = wave, wg_jn = -1;
+    const int64_t wg_first = t_first - wave;
 #pragma unroll 1
-    for (int64_t ts = t_first; ts < n_tiles; ts += nw) {
+    for (int64_t tp = t_first; tp < pool_tiles; tp = kWgDyn ? wg_first + (int64_t)(wg_j / kWaves) * nw + (wg_j % kWaves) : tp + nw) {
+        const int64_t ts = pool_base + tp;
         // Odd steps walk the tiles backwards: what the previous step wrote last is read first, while it is still
         // in the 256 MB Infinity Cache.  Irrelevant at N = 2^20 (the whole working set fits), 208 -> 159 us per
         // step at N = 2^22 (800 MB working set: 3.8 -> 5.0 TB/s algorithmic).
         const int64_t t = (step_index & 1) ? (n_tiles - 1 - ts) : ts;
+#if R6_PRIO_REMAINING
+        {   // priority = tiles this wave still has to do after this one (capped at 3): a wave that owns one tile more
+            // than its neighbours runs its first tile ahead of them instead of its last one behind them
+            const int64_t left = (pool_tiles - 1 - tp) / nw;
+            if (left >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (left == 2) __builtin_amdgcn_s_setprio(2);
+            else if (left == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#else
         if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
         else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
         else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
+#endif
         ++tile_no;
         TileIn cur;
         bool overflow;
+#ifdef R6_TRACE   // dev build (scripts/trace_timeline.py): per wave and tile, 100 MHz stamps around the load / compute / store phases
+        uint32_t* trc = reinterpret_cast<uint32_t*>(b.stats) + ((int64_t)blockIdx.x * kWaves + wave) * 24;
+        const uint32_t tr_a = (uint32_t)wall_clock64();
+#endif
         if (t < n_full) {
             if constexpr (kPrefetch) {
                 // The Euler step has too little arithmetic to cover its own loads: the next tile's inputs are
@@ -427,14 +488,42 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
                 // before this tile is computed: 37.0 -> 34.7 us.  The same costs the RK4 instance 1.2 us.
                 if (have_nxt) cur = nxt;
                 else load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
-                const int64_t tsn = ts + nw;
+                int64_t tpn = tp + nw;
+                if constexpr (kWgDyn) {   // the tile after this one is claimed now, so that its inputs can be requested
+                    int nj = 0;
+                    if (lane == 0) nj = atomicAdd(&wg_next, 1);
+                    wg_jn = __builtin_amdgcn_readfirstlane(nj);
+                    tpn = wg_first + (int64_t)(wg_jn / kWaves) * nw + (wg_jn % kWaves);
+                }
+                const int64_t tsn = pool_base + tpn;
                 const int64_t tn = (step_index & 1) ? (n_tiles - 1 - tsn) : tsn;
-                have_nxt = tsn < n_tiles && tn < n_full;
+                have_nxt = tpn < pool_tiles && tn < n_full;
                 if (have_nxt) load_tile<SHAPING, true>(b, has_ep, tn * 64, lane, nxt);
             } else {
                 load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
             }
+#ifdef R6_TRACE
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint32_t tr_b = (uint32_t)wall_clock64();
+#endif
             overflow = process_tile(t * 64, cur, std::true_type{});
+#ifdef R6_TRACE
+            const uint32_t tr_c = (uint32_t)wall_clock64();
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint32_t tr_d = (uint32_t)wall_clock64();
+            if (b.stats && lane == 0 && tile_no <= 5) {
+                if (tile_no == 1) {
+                    trc[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+                    trc[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+                    trc[2] = (uint32_t)pt0;
+                }
+                trc[3] = tile_no;
+                trc[4 * tile_no + 0] = tr_a;
+                trc[4 * tile_no + 1] = tr_b;
+                trc[4 * tile_no + 2] = tr_c;
+                trc[4 * tile_no + 3] = tr_d;
+            }
+#endif
         } else {
             have_nxt = false;
             load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
@@ -446,14 +535,26 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
             __builtin_amdgcn_s_waitcnt(0);
             if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
         }
+        if constexpr (kWgDyn) {
+            if (wg_jn >= 0) {   // claimed ahead by the prefetch
+                wg_j = wg_jn;
+                wg_jn = -1;
+            } else {            // partial tile / no prefetch issued: claim now (lane 0 asks, the wave reads the answer as a scalar)
+                int nj = 0;
+                if (lane == 0) nj = atomicAdd(&wg_next, 1);
+                wg_j = __builtin_amdgcn_readfirstlane(nj);
+            }
+        }
     }
     __builtin_amdgcn_s_setprio(0);
 
 #ifdef R6_PHASE_TIMING
     const uint64_t pt1 = wall_clock64();
 #endif
-    // __syncthreads() drains every wave's outstanding stores (s_waitcnt vmcnt(0)) before the barrier,
-    // so the drain below overwrites the terminal state / obs of the finished envs in order.
+    // Every wave waits for its own outstanding stores before the barrier (the workgroup-scope fence of __syncthreads()
+    // does not emit a vmcnt wait on gfx9, so the wait is explicit): the drain below overwrites the terminal state /
+    // obs of the finished envs, and those stores must have been acknowledged by L2 first.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 #ifdef R6_PHASE_TIMING
     const uint64_t pt2 = wall_clock64();
@@ -462,8 +563,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     const int n_queued = rq_count;
     if (n_queued > 0) {
         const R6Buffers bb = load_buffers();
-#ifndef R6_PHASE_TIMING
-        if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
+#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE)
+        if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += (double)blk_stats[tid];
 #endif
 
         // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
@@ -473,26 +574,240 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
             reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
     } else if (!p.auto_reset) {
         const R6Buffers bb = load_buffers();
-#ifndef R6_PHASE_TIMING
+#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE)
         if (bb.stats && tid < R6_NUM_STATS && blk_stats[0] > 0.0f)
-            bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += blk_stats[tid];
+            bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += (double)blk_stats[tid];
 #endif
     }
 #ifdef R6_PHASE_TIMING
     if (b.stats && (tid & 63) == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         const uint64_t pt3 = wall_clock64();
-        float* o = b.stats + (int64_t)blockIdx.x * R6_NUM_STATS;
+        double* o = b.stats + (int64_t)blockIdx.x * R6_NUM_STATS;   // stamps as exact integers in float64
         if (tid == 0) {
-            o[0] = __uint_as_float((uint32_t)pt0);
-            o[2] = __uint_as_float((uint32_t)pt2);
-            o[3] = __uint_as_float((uint32_t)pt3);
-            o[7] = __uint_as_float((uint32_t)n_queued);
+            o[0] = (double)(uint32_t)pt0;
+            o[2] = (double)(uint32_t)pt2;
+            o[3] = (double)(uint32_t)pt3;
+            o[7] = (double)n_queued;
         }
         // per-wave end of the tile loop: slots 1 (wave 0), 4, 5, 6 (waves 1..3)
-        o[wave == 0 ? 1 : 3 + wave] = __uint_as_float((uint32_t)pt1);
+        o[wave == 0 ? 1 : 3 + wave] = (double)(uint32_t)pt1;
     }
 #endif
+}
+
+// -------------------------------------------------------------------------------------------------
+// K consecutive Rocket6DOF.step calls in ONE launch (r6_step_k).
+//
+// The rollout loop of the reference (main_6DOF.py:136-139: model.learn -> env.step per timestep) pays one kernel
+// launch per env step; at N = 65 536 (BASELINE configs[1]) a step is 1.5 us of memory time behind ~10 us of launch
+// latency.  Here a wave keeps the state of its 64 envs in registers across K steps: per step it reads the 3-float
+// action of step k and writes that step's observation / reward / done (and the optional outputs); state rows and
+// episode counters are read once before and written once after the K steps.  Finished episodes are re-sampled in
+// the lane itself (the same Philox draw, keyed by (seed, global env, global step), that the single-step kernel's
+// dense drain makes), so K fused steps produce bit for bit what K r6_step launches produce.
+//
+// Per-step arrays carry a leading K dimension with the strides of R6StepK (0 = every step overwrites the same
+// buffer, i.e. only the last step's outputs survive -- R6_K_LAST_ONLY skips the earlier stores altogether).
+// -------------------------------------------------------------------------------------------------
+template <int INTEG, int SHAPING, int OD, bool ONE>
+__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_kernel(const R6Params p, const R6Buffers b, const R6StepK sk,
+                                                                               const uint64_t seed, const uint64_t step_index,
+                                                                               const uint64_t env_offset) {
+    __shared__ __attribute__((aligned(16))) float tiles[kWaves][64 * OD];
+    __shared__ float lds_inv_norm[R6_STATE_DIM];
+    __shared__ float blk_stats[R6_NUM_STATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* tile = tiles[wave];
+    const int64_t n = b.n, ld = b.ld;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t nw = (int64_t)gridDim.x * kWaves;
+    const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
+    const int K = sk.k;
+    const bool last_only = (sk.flags & R6_K_LAST_ONLY) != 0;
+
+    if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
+    if (tid < R6_STATE_DIM) lds_inv_norm[tid] = p.inv_norm[tid];
+    __syncthreads();
+
+#pragma unroll 1
+    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += nw) {
+        const int64_t e0 = t * 64;
+        const int64_t rem = n - e0;
+        const bool live = lane < rem;
+        const bool full = rem >= 64;
+        const int64_t i = e0 + lane;   // this lane's env (valid when live)
+
+        // ---- state of the tile: read once ------------------------------------------------------------------
+        float y[kDyn], mass = 4.0e4f, m0 = 4.0e4f, v0 = 0.0f, ep_ret = 0.0f;
+        uint32_t ep_step = 0u;
+#pragma unroll
+        for (int j = 0; j < kDyn; ++j) y[j] = (j == 0) ? 1000.0f : ((j == 6) ? 1.0f : 0.0f);   // benign padding lane
+        if (live) {
+            const float* row = b.state + e0;
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) {
+                y[j] = uniform_ptr(row)[lane];
+                row += ld;
+            }
+            mass = uniform_ptr(row)[lane];
+            m0 = uniform_ptr(b.epconst + e0)[lane];
+            v0 = uniform_ptr(b.epconst + (ld + e0))[lane];   // read for either shaping: a reset rewrites it, like r6_step's drain
+            if (has_ep) {
+                ep_step = uniform_ptr(b.ep_step + e0)[lane];
+                ep_ret = uniform_ptr(b.ep_return + e0)[lane];
+            }
+        }
+        float a0 = 0.0f, a1 = 0.0f, a2 = -1.0f;
+        if (live) {
+            const gptr<const float> act = uniform_ptr(b.action + e0 * R6_ACTION_DIM);
+            a0 = act[3 * lane + 0];
+            a1 = act[3 * lane + 1];
+            a2 = act[3 * lane + 2];
+        }
+
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            // next step's action is requested before this step is computed
+            float n0 = 0.0f, n1 = 0.0f, n2 = -1.0f;
+            if (live && k + 1 < K) {
+                const gptr<const float> act = uniform_ptr(b.action + ((int64_t)(k + 1) * sk.action_stride + e0 * R6_ACTION_DIM));
+                n0 = act[3 * lane + 0];
+                n1 = act[3 * lane + 1];
+                n2 = act[3 * lane + 2];
+            }
+            const bool emit = !last_only || k + 1 == K;   // wave-uniform: this step's outputs leave the chip
+
+            // ---- dynamics (sim:69-143) ---------------------------------------------------------------------
+            const Control c = make_control_normalised(p, a0, a1, a2);
+            const Inertia J = make_inertia(m0);
+            int nfev = 0, status;
+            if constexpr (INTEG == R6_RK45) {
+                status = integrate_rk45(y, mass, c, J, p.dt, nfev);
+            } else {
+                status = integrate<INTEG, true, ONE>(y, mass, c, J, p.dt, p.n_substeps);
+                nfev = (INTEG == R6_RK4 ? 4 : 1) * (ONE ? 1 : p.n_substeps);
+            }
+
+            // ---- termination, reward, fused wrappers: the same sequence as step_kernel ---------------------------
+            const R6Params pr = load_params();
+            const bool bnd = bounds_violation(pr, y[0], y[1], y[2]);
+            bool done = (status != 0) || bnd, truncated = false;
+            RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
+            const bool landed = rw.landed;
+            float rew = finalize_reward(pr, rw, bnd, fmaf(2.0f * c.thrust, frcp(pr.max_thrust), -1.0f), y);
+            if (live && emit && b.terms) {
+                float* trow = b.terms + ((int64_t)k * sk.terms_stride + i);
+#pragma unroll
+                for (int q = 0; q < R6_NUM_TERMS; ++q) {
+                    *trow = rw.terms[q];
+                    trow += ld;
+                }
+            }
+            if (pr.clip_reward) rew = fminf(fmaxf(rew, pr.clip_lo), pr.clip_hi);
+            ep_step += 1u;
+            ep_ret += rew;
+            if (pr.max_episode_steps > 0 && ep_step >= (uint32_t)pr.max_episode_steps) {
+                truncated = !done;
+                done = true;
+            }
+
+            // ---- per-step outputs -----------------------------------------------------------------------------------
+            if (live && emit) {
+                uniform_ptr(b.reward + ((int64_t)k * sk.reward_stride + e0))[lane] = rew;
+                uniform_ptr(b.done + ((int64_t)k * sk.done_stride + e0))[lane] = done ? 1 : 0;
+                if (b.flags)
+                    uniform_ptr(b.flags + ((int64_t)k * sk.flags_stride + e0))[lane] =
+                        (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
+                if (b.nfev) uniform_ptr(b.nfev + ((int64_t)k * sk.nfev_stride + e0))[lane] = (uint8_t)(nfev > 255 ? 255 : nfev);
+            }
+            // observation (env:503-504): registers -> LDS row-major tile
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) {
+                if (j < OD) tile[lane * OD + j] = y[j] * lds_inv_norm[j];
+            }
+            if (OD == 14) tile[lane * OD + (OD - 1)] = mass * lds_inv_norm[13];
+
+            // ---- finished episodes: terminal outputs, statistics, and Rocket6DOF.reset (env:180-199) in the lane -----
+            if (live && done) {
+                if (b.stats) {
+                    atomicAdd(&blk_stats[R6_STAT_EPISODES], 1.0f);
+                    atomicAdd(&blk_stats[R6_STAT_RETURN], ep_ret);
+                    atomicAdd(&blk_stats[R6_STAT_RETURN_SQ], ep_ret * ep_ret);
+                    atomicAdd(&blk_stats[R6_STAT_LENGTH], (float)ep_step);
+                    if (status == 1) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
+                    if (bnd) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
+                    if (truncated) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
+                    if (landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
+                }
+                if (p.auto_reset) {
+                    if (emit) {
+                        if (b.final_obs) {
+                            float* fo = b.final_obs + ((int64_t)k * sk.final_obs_stride + i * OD);
+#pragma unroll
+                            for (int j = 0; j < OD; ++j) fo[j] = tile[lane * OD + j];
+                        }
+                        if (b.fin_return) b.fin_return[(int64_t)k * sk.fin_stride + i] = ep_ret;
+                        if (b.fin_length) b.fin_length[(int64_t)k * sk.fin_stride + i] = ep_step;
+                    }
+                    float ic[R6_STATE_DIM];
+                    sample_ic(load_params(), seed, env_offset + (uint64_t)i, step_index + (uint64_t)k, ic);
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) y[j] = ic[j];
+                    mass = m0 = ic[13];
+                    v0 = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
+                    ep_step = 0u;
+                    ep_ret = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) tile[lane * OD + j] = ic[j] * lds_inv_norm[j];   // the fresh episode's first observation
+                }
+            }
+
+            // ---- LDS tile -> contiguous 16 B-per-lane stores of this step's (64, OD) observation block -----------------
+            wave_lds_sync();
+            if (emit) {
+                const gptr<float> dst = uniform_ptr(b.obs + ((int64_t)k * sk.obs_stride + e0 * OD));
+                if (full) {
+                    constexpr int n4 = 64 * OD / 4;
+#pragma unroll
+                    for (int r = 0; r < (n4 + 63) / 64; ++r) {
+                        const int q = lane + 64 * r;
+                        if (q < n4) *(gptr<f4>)(dst + 4 * q) = ld4(&tile[4 * q]);
+                    }
+                } else {
+                    for (int q = lane; q < (int)rem * OD; q += 64) dst[q] = tile[q];
+                }
+            }
+            wave_lds_sync();
+            a0 = n0;
+            a1 = n1;
+            a2 = n2;
+        }
+
+        // ---- state of the tile: written once -----------------------------------------------------------------
+        if (live) {
+            float* row = b.state + e0;
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) {
+                uniform_ptr(row)[lane] = y[j];
+                row += ld;
+            }
+            uniform_ptr(row)[lane] = mass;
+            uniform_ptr(b.epconst + e0)[lane] = m0;
+            uniform_ptr(b.epconst + (ld + e0))[lane] = v0;
+            if (has_ep) {
+                uniform_ptr(b.ep_step + e0)[lane] = ep_step;
+                uniform_ptr(b.ep_return + e0)[lane] = ep_ret;
+            }
+        }
+    }
+
+    __syncthreads();
+    if (b.stats && tid < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] > 0.0f)
+        b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += (double)blk_stats[tid];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -598,7 +913,7 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + r6::kBlock - 1) / 
 // Resident capacity (workgroups) of the current device for one step-kernel instance, cached.
 template <typename K>
 int resident_blocks(K kernel, int slot) {
-    static std::atomic<int> cache[16][16];
+    static std::atomic<int> cache[16][32];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     int v = cache[dev][slot].load(std::memory_order_relaxed);
@@ -615,6 +930,25 @@ int resident_blocks(K kernel, int slot) {
     if (v > R6_MAX_BLOCKS) v = R6_MAX_BLOCKS;
     cache[dev][slot].store(v, std::memory_order_relaxed);
     return v;
+}
+
+// Share of the tiles handed to the workgroups on even XCDs, in 1/65536 (0 = no split).  Defaults from a sweep at
+// N = 2^20 (0.50 / 0.52 / 0.54 / 0.56: RK4 39.5 / 38.8 / 38.3 / 38.6 us, fused stack 43.6 / 42.8 / 41.8 / 41.5, Euler 35.2 /
+// 35.3 / 35.2 / 34.1): the even XCDs of an MI355X finish equal shares ~1.19x sooner (load latency, see step_kernel).
+// R6_EVEN_XCD_SHARE=<fraction> overrides (0 or 0.5 = equal shares); results do not depend on it, only which wave
+// computes which tile.
+#ifndef R6_EVEN_SHARE_DEFAULT
+#define R6_EVEN_SHARE_DEFAULT -1.0   // < 0: per-integrator default (RK4 0.54, Euler 0.56)
+#endif
+uint32_t even_xcd_share_q16(int integrator) {
+    static const double forced = [] {
+        double f = R6_EVEN_SHARE_DEFAULT;
+        if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) f = std::atof(e);
+        return f;
+    }();
+    const double f = forced >= 0.0 ? forced : (integrator == R6_EULER ? 0.56 : 0.54);
+    if (!(f > 0.0) || f == 0.5 || f >= 1.0) return 0u;
+    return (uint32_t)(f * 65536.0 + 0.5);
 }
 
 template <int INTEG, int SHAPING, int OD>
@@ -640,7 +974,32 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
         const int64_t big = n_tiles / (2 * r6::kWaves);
         blocks = (!pinned && n_tiles >= 49152 && big > cap) ? (big < R6_MAX_BLOCKS ? big : R6_MAX_BLOCKS) : cap;
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off);
+    // XCD-aware split (see step_kernel): only for the persistent grid, where every wave walks several tiles
+    uint32_t even_share = 0;
+    if (blocks == cap && (blocks % 8) == 0 && n_tiles >= 2 * blocks * r6::kWaves) even_share = even_xcd_share_q16(INTEG);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share);
+}
+
+template <int INTEG, int SHAPING, int OD>
+void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
+    auto kernel = r6::step_k_kernel<INTEG, SHAPING, OD, false>;
+    if constexpr (INTEG != R6_RK45) {
+        if (p.n_substeps == 1) kernel = r6::step_k_kernel<INTEG, SHAPING, OD, true>;
+    }
+    const int slot = 16 + INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);
+    const int64_t n_tiles = (b.n + 63) / 64;
+    int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
+    const int cap = resident_blocks(kernel, slot);
+    if (blocks > cap) blocks = cap;   // persistent waves: a tile's K steps are serial, tiles are spread over the resident grid
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, sk, seed, step, off);
+}
+
+template <int INTEG, int SHAPING>
+void launch_step_k_od(const R6Params& p, const R6Buffers& b, const R6StepK& sk, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
+    if (p.obs_dim == 14)
+        launch_step_k_inst<INTEG, SHAPING, 14>(p, b, sk, seed, step, off, s);
+    else
+        launch_step_k_inst<INTEG, SHAPING, 13>(p, b, sk, seed, step, off, s);
 }
 
 template <int INTEG, int SHAPING>
@@ -692,6 +1051,41 @@ int r6_step(const R6Params* params, const R6Buffers* buf, uint64_t seed, uint64_
             launch_step_od<R6_EULER, R6_SHAPING_VELOCITY>(p, b, seed, step_index, env_offset, s);
     }
     return check_launch("r6_step");
+}
+
+size_t r6_stepk_size(void) { return sizeof(R6StepK); }
+
+int r6_step_k(const R6Params* params, const R6Buffers* buf, const R6StepK* steps, uint64_t seed, uint64_t step_index,
+              uint64_t env_offset, void* stream) {
+    if (int rc = validate_common(params, buf)) return rc;
+    if (!steps) return fail(R6_E_BADARG, "r6_step_k: null R6StepK");
+    const R6Buffers& b = *buf;
+    const R6StepK& sk = *steps;
+    if (sk.k < 1 || sk.k > 65536) return fail(R6_E_BADARG, "r6_step_k: k must be in 1..65536");
+    if (b.n == 0) return 0;
+    if (!b.state || !b.epconst || !b.action || !b.obs || !b.reward || !b.done)
+        return fail(R6_E_BADARG, "r6_step_k: state/epconst/action/obs/reward/done are required");
+    if (!aligned16(b.action) || !aligned16(b.obs))
+        return fail(R6_E_ALIGN, "r6_step_k: action and obs must be 16-byte aligned");
+    if (sk.action_stride < 0 || sk.obs_stride < 0 || sk.reward_stride < 0 || sk.done_stride < 0 || sk.flags_stride < 0 ||
+        sk.nfev_stride < 0 || sk.terms_stride < 0 || sk.final_obs_stride < 0 || sk.fin_stride < 0)
+        return fail(R6_E_BADARG, "r6_step_k: strides must be >= 0");
+    if (sk.k > 1 && sk.action_stride < b.n * R6_ACTION_DIM) return fail(R6_E_BADARG, "r6_step_k: action_stride must be >= 3 n");
+    if ((sk.obs_stride % 4) != 0) return fail(R6_E_ALIGN, "r6_step_k: obs_stride must be a multiple of 4 elements (16-byte stores)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const R6Params& p = *params;
+    const bool acc = p.shaping == R6_SHAPING_ACCELERATION;
+    if (p.integrator == R6_RK45) {
+        if (acc) launch_step_k_od<R6_RK45, R6_SHAPING_ACCELERATION>(p, b, sk, seed, step_index, env_offset, s);
+        else launch_step_k_od<R6_RK45, R6_SHAPING_VELOCITY>(p, b, sk, seed, step_index, env_offset, s);
+    } else if (p.integrator == R6_RK4) {
+        if (acc) launch_step_k_od<R6_RK4, R6_SHAPING_ACCELERATION>(p, b, sk, seed, step_index, env_offset, s);
+        else launch_step_k_od<R6_RK4, R6_SHAPING_VELOCITY>(p, b, sk, seed, step_index, env_offset, s);
+    } else {
+        if (acc) launch_step_k_od<R6_EULER, R6_SHAPING_ACCELERATION>(p, b, sk, seed, step_index, env_offset, s);
+        else launch_step_k_od<R6_EULER, R6_SHAPING_VELOCITY>(p, b, sk, seed, step_index, env_offset, s);
+    }
+    return check_launch("r6_step_k");
 }
 
 int r6_reset(const R6Params* params, const R6Buffers* buf, const uint8_t* mask, uint64_t seed, uint64_t step_index,

@@ -61,6 +61,25 @@ def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str
     return {k: float(tot[i]) for i, k in enumerate(STAT_NAMES)}, table
 
 
+def reduce_bench_times(wall_s: float, kernel_ms: float, device=None) -> Dict[str, object]:
+    """Min / max over ranks of a rank's wall time and per-step kernel time (bench.py: the job's time is the slowest
+    rank's), plus the device index every rank ran on.  One all-gather of three float64 per rank: through the device for
+    RCCL (backend nccl), on the host for gloo; the identity without a process group."""
+    dev_index = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    vec = torch.tensor([wall_s, kernel_ms, float(dev_index)], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            vec = vec.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        rows = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, vec)
+        table = torch.stack(rows).cpu()
+    else:
+        table = vec.reshape(1, 3)
+    return {"wall_max": float(table[:, 0].max()), "wall_min": float(table[:, 0].min()),
+            "kernel_ms_max": float(table[:, 1].max()), "kernel_ms_min": float(table[:, 1].min()),
+            "devices": [int(x) for x in table[:, 2].tolist()]}
+
+
 def summarize(tot: Dict[str, float]) -> Dict[str, float]:
     n = max(tot["episodes"], 1.0)
     mean = tot["return_sum"] / n

@@ -66,6 +66,19 @@ class R6Buffers(C.Structure):
     ]
 
 
+K_LAST_ONLY = 1
+
+
+class R6StepK(C.Structure):
+    """include/r6dof.h ``R6StepK``: K env steps per launch, element strides of the per-step arrays."""
+    _fields_ = [
+        ("k", C.c_int32), ("flags", C.c_int32),
+        ("action_stride", C.c_int64), ("obs_stride", C.c_int64), ("reward_stride", C.c_int64), ("done_stride", C.c_int64),
+        ("flags_stride", C.c_int64), ("nfev_stride", C.c_int64), ("terms_stride", C.c_int64),
+        ("final_obs_stride", C.c_int64), ("fin_stride", C.c_int64),
+    ]
+
+
 class R6PolicyNet(C.Structure):
     """include/r6dof.h ``R6PolicyNet``: device pointers to fp32 weights in torch.nn.Linear layout."""
     _fields_ = [

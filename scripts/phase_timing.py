@@ -27,7 +27,7 @@ for k in range(10):
     env.stats.zero_()
     env.step_async(pool[k % 8])
     torch.cuda.synchronize()
-    s = env.stats.view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    s = env.stats.cpu().numpy().astype(np.int64) & 0xFFFFFFFF   # stamps are stored as exact integers in float64
     s = s[s[:, 0] != 0]
     t0 = s[:, 0].min()
     us = lambda col: (s[:, col] - t0) / 100.0
@@ -35,7 +35,7 @@ for k in range(10):
     rows.append([len(s), us(0).max(), wave_end.min(), wave_end.mean(), wave_end.max(), us(2).mean(), us(2).max(),
                  us(3).mean(), us(3).max(), s[:, 7].mean(), s[:, 7].max()])
     if k == 9:
-        blk = np.nonzero(env.stats.view(torch.int32).cpu().numpy()[:, 0] != 0)[0]
+        blk = np.nonzero(env.stats.cpu().numpy()[:, 0] != 0)[0]
         n_tiles, nw = n // 64, len(blk) * 4
         heavy = blk * 4 < n_tiles - (n_tiles // nw) * nw        # workgroups whose waves own one tile more
         for name, m in (("heavy", heavy), ("light", ~heavy)):

@@ -33,12 +33,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_mirrors_match_header_and_library():
     from rl_rocket_6dof_amd import _lib
-    from rl_rocket_6dof_amd.params import NUM_STATS, NUM_TERMS, STATE_DIM, MAX_BLOCKS, R6Buffers, R6Params
+    from rl_rocket_6dof_amd.params import NUM_STATS, NUM_TERMS, STATE_DIM, MAX_BLOCKS, R6Buffers, R6Params, R6StepK
 
     lib = _lib.load()
     assert lib.r6_abi_version() == _lib.ABI_VERSION
     assert lib.r6_params_size() == C.sizeof(R6Params)
     assert lib.r6_buffers_size() == C.sizeof(R6Buffers)
+    assert lib.r6_stepk_size() == C.sizeof(R6StepK)
     src = open(HEADER).read()
     consts = dict(re.findall(r"#define\s+(R6_[A-Z_]+)\s+(\d+)", src))
     assert int(consts["R6_STATE_DIM"]) == STATE_DIM and int(consts["R6_NUM_TERMS"]) == NUM_TERMS
@@ -54,6 +55,9 @@ def test_ctypes_mirrors_match_header_and_library():
         for name in decl.split(None, 1)[1].split(","):
             hdr_fields.append(re.sub(r"\[.*\]", "", name).strip())
     assert hdr_fields == [f[0] for f in R6Params._fields_]
+    body = re.search(r"typedef struct R6StepK \{(.*?)\} R6StepK;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert [d.split()[-1] for d in body.split(";") if d.strip()] == [f[0] for f in R6StepK._fields_]
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -72,6 +76,12 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.r6_step(C.byref(p), C.byref(b), 0, 1, 0, None) == -10001
     p.obs_dim = 12
     assert lib.r6_step(C.byref(p), C.byref(b), 0, 1, 0, None) == -10001
+    p.obs_dim = 14
+    from rl_rocket_6dof_amd.params import R6StepK
+
+    assert lib.r6_step_k(C.byref(p), C.byref(b), None, 0, 1, 0, None) == -10001          # no R6StepK
+    assert lib.r6_step_k(C.byref(p), C.byref(b), C.byref(R6StepK(k=0)), 0, 1, 0, None) == -10001
+    assert b"k must be" in lib.r6_last_error()
 
 
 def test_derived_quantities_match_reference():

@@ -1,0 +1,96 @@
+"""bench.py's argument handling and line building without a GPU: the N > 1 branch (rank reduction over gloo with world
+size 2, the `rccl` object, whole-job value) must not meet its first typo on the 8-GPU box."""
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_line_contract_single_gpu():
+    args = bench.parse_args([])
+    assert (args.gpus, args.steps, args.warmup, args.k) == (1, 2000, 200, 1)
+    n = args.envs_per_gpu
+    line = bench.build_line(args, 1, n, 0.1, wall=2000 * 38e-6, kernel_ms=0.0375, traffic=2.04e8,
+                            traffic_source="profiles/x.json (static file)", extras={"cpu_baseline": {"value": 2300.0}})
+    json.loads(json.dumps(line))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f32"
+    assert abs(line["value"] - n / 38e-6) < 1e-3 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["achieved"] - 189 * n / 37.5e-6 / 1e9) < 1e-6 * r["achieved"] and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["traffic_source"].startswith("profiles/") and abs(r["kernel_us"] - 37.5) < 1e-9
+    assert "model" not in line["config"] and "workload" in line["config"]
+
+
+def test_bytes_per_env_step_formula():
+    assert bench.bytes_per_env_step("raw") == 189 and bench.bytes_per_env_step("wrapped") == 201
+    # K steps per launch: action 12 + obs 56 + reward 4 + done 1 per step, state 2 x 56 + epconst 2 x 8 once per K steps
+    assert bench.bytes_per_env_step("raw", 16) == pytest.approx(73 + 128 / 16)
+    assert bench.bytes_per_env_step("raw", 1 << 30) == pytest.approx(73, rel=1e-6)
+
+
+def test_k_must_divide_steps():
+    with pytest.raises(SystemExit):
+        bench.main(["--k", "16", "--steps", "100"])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench as b
+    from rl_rocket_6dof_amd import dist as r6dist
+
+    r, w, _ = r6dist.init_from_env(backend="gloo")
+    # what main() does after its timed loops, with the GPU part replaced by fixed per-rank numbers
+    wall, kernel_ms = (0.080, 0.0380) if rank == 0 else (0.084, 0.0402)
+    red = r6dist.reduce_bench_times(wall, kernel_ms)
+    tot, _ = r6dist.gather_episode_stats({k: float(rank + 1) for k in r6dist.STAT_NAMES})
+    args = b.parse_args(["--gpus", "2", "--steps", "2000", "--warmup", "100"])
+    extras = {"rccl": {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
+                       "kernel_us_min": red["kernel_ms_min"] * 1e3, "kernel_us_max": red["kernel_ms_max"] * 1e3,
+                       "with_rollout_gather": {"gather_every": args.gather_every, "episodes_seen": tot["episodes"]}}}
+    line = b.build_line(args, w, args.envs_per_gpu, 0.1, red["wall_max"], red["kernel_ms_max"], extras=extras)
+    q.put((rank, json.dumps(line)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_line_over_gloo():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    l0, l1 = json.loads(res[0]), json.loads(res[1])
+    assert l0["n_gpus"] == 2 and l0["config"]["envs_total"] == 2 * (1 << 20)
+    # whole-job value over the SLOWEST rank's time; both ranks agree on every reduced number
+    assert l0["value"] == pytest.approx(2 * (1 << 20) * 2000 / 0.084) and l0["value"] == l1["value"]
+    assert l0["roofline"]["kernel_us"] == pytest.approx(40.2) and l0["rccl"]["kernel_us_min"] == pytest.approx(38.0)
+    assert l0["rccl"]["rccl_ranks"] == 2 and l0["rccl"]["backend"] == "gloo"
+    assert l0["rccl"]["with_rollout_gather"]["episodes_seen"] == 3.0
+    assert l0["roofline"]["traffic"] is None and l0["roofline"]["traffic_source"] is None
