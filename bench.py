@@ -131,9 +131,16 @@ def parse_args(argv=None):
 
 
 def git_commit() -> str:
+    """Commit of the sources: from git where .git exists, else the stamp the build left next to the library."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or "unknown"
+        rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                             timeout=10).stdout.strip()
+        if rev:
+            return rev
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "rl_rocket_6dof_amd", "csrc", "BUILD_COMMIT")).read().strip() or "unknown"
     except Exception:
         return "unknown"
 

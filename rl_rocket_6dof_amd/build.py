@@ -49,7 +49,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print("[rl_rocket_6dof_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(LIB + ".tmp", LIB)
+    _stamp_commit()
     return LIB
+
+
+COMMIT_FILE = os.path.join(CSRC, "BUILD_COMMIT")
+
+
+def _stamp_commit():
+    """Records the source commit next to the library (git-ignored; travels with the .so to machines without .git, where
+    bench.py reports it)."""
+    try:
+        root = os.path.join(HERE, "..")
+        rev = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "rl_rocket_6dof_amd/csrc", "include"], capture_output=True,
+                               text=True, timeout=10).stdout.strip()
+        if rev:
+            with open(COMMIT_FILE, "w") as f:
+                f.write(rev + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

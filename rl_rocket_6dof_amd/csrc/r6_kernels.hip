@@ -48,6 +48,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef R6_PRIO_REMAINING
 #define R6_PRIO_REMAINING 0     // A/B switch: wave priority from the tiles left (1: measured 0.4-1.6 us slower) or from the tiles done (0)
 #endif
+#ifndef R6_ACT_LDS
+#define R6_ACT_LDS 0            // A/B switch: action edge staged through LDS (1) or one 12-byte load per lane (0)
+#endif
 #ifndef R6_WG_DYNAMIC
 #define R6_WG_DYNAMIC 1         // A/B switch (Euler instances): the waves of a workgroup pull the workgroup's tiles from an LDS counter (1) or own fixed lists (0)
 #endif
@@ -139,7 +142,7 @@ struct TileIn {
 };
 
 template <int SHAPING, bool FULL>
-__device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64_t e0, int lane, TileIn& in) {
+__device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64_t e0, int lane, TileIn& in, float* lds = nullptr) {
     const int64_t ld = b.ld;
     const bool live = FULL ? true : (lane < b.n - e0);
     in.mass = in.m0 = 4.0e4f;
@@ -163,9 +166,29 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
             in.ep_ret = uniform_ptr(b.ep_return + e0)[lane];
         }
         const gptr<const float> act = uniform_ptr(b.action + e0 * R6_ACTION_DIM);
-        in.a0 = act[3 * lane + 0];  // 3 x 4 B at a 12 B lane stride: the wave touches the same 768 B
-        in.a1 = act[3 * lane + 1];  // three times, the repeats are L1 hits
-        in.a2 = act[3 * lane + 2];
+#if R6_ACT_LDS
+        // A/B variant: the (64,3) action block staged through the wave's LDS tile -- three coalesced 256 B loads,
+        // row-major image in LDS, read back at a 3-word lane stride (conflict-free: 3 is odd).
+        if constexpr (FULL) {
+            const float g0 = act[lane], g1 = act[lane + 64], g2 = act[lane + 128];
+            lds[lane] = g0;
+            lds[lane + 64] = g1;
+            lds[lane + 128] = g2;
+            wave_lds_sync();
+            in.a0 = lds[3 * lane + 0];
+            in.a1 = lds[3 * lane + 1];
+            in.a2 = lds[3 * lane + 2];
+            wave_lds_sync();
+        } else
+#endif
+        {
+            // 12 contiguous bytes per lane: the compiler issues ONE global_load_dwordx3 per lane, i.e. the wave reads its
+            // 768 B action block with a single instruction over 6 whole cache lines -- already the access an LDS-staged
+            // edge would make, without the LDS round trip (A/B with R6_ACT_LDS=1: DESIGN.md section 4).
+            in.a0 = act[3 * lane + 0];
+            in.a1 = act[3 * lane + 1];
+            in.a2 = act[3 * lane + 2];
+        }
     }
 }
 
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
                 have_nxt = tpn < pool_tiles && tn < n_full;
                 if (have_nxt) load_tile<SHAPING, true>(b, has_ep, tn * 64, lane, nxt);
             } else {
-                load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
+                load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
             }
 #ifdef R6_TRACE
             __builtin_amdgcn_s_waitcnt(0);
