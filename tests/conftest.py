@@ -67,9 +67,19 @@ def g6():
 PARITY_LOG = {}
 
 
+def pure_rel_err(a, b, scale, floor=0.05):
+    """Worst |a-b| / |b| over the entries whose reference is not tiny (|b| >= floor * scale)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.broadcast_to(np.asarray(scale, dtype=np.float64), b.shape)
+    m = np.abs(b) >= floor * scale
+    return float((np.abs(a - b)[m] / np.abs(b[m])).max()) if m.any() else 0.0
+
+
 def _log_key(what):
     import re
 
+    what = re.sub(r"^step \d+: ", "", str(what))
     return re.sub(r"[\s:]*(step|env|case|episode|rollout)?\s*\d+(\s+(step|env)\s*\d+)*\s*$", "", str(what)).strip()
 
 

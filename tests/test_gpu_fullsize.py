@@ -69,12 +69,12 @@ def test_rollout_vs_c_oracle_sampled(torch_cuda, cfg, integ, dt):
             got_obs = np.where(d[:, None], env.final_obs[sel].cpu().numpy(), obs[sel].cpu().numpy())
             e = np.abs(got_obs - ref.obs) / np.maximum(np.abs(ref.obs), 1.0)
             worst = max(worst, float(e.max()))
-            assert e.max() < 1e-5
+            assert e.max() < 2e-6, f"obs vs C oracle: {e.max():.2e}"     # measured on MI355X: 2e-7 (rk4), events included up to 4e-7
             np.testing.assert_allclose(rew[sel].cpu().numpy(), ref.reward, rtol=1e-5, atol=1e-5)
             post = env.get_state()[sel].cpu().numpy()
             nd = ~d
             err = np.abs(post[nd] - ref.state[nd]) / np.maximum(np.abs(ref.state[nd]), P.normalizer)
-            assert err.max() < 1e-5
+            assert err.max() < 2e-6, f"post-state vs C oracle: {err.max():.2e}"
             for j in np.nonzero(d)[0][:8]:   # freshly reset envs: exactly the oracle's Philox sample
                 want = onp.reset_sample(42, int(idx[j]), env._step_count, P)
                 plain = [0, 1, 2, 3, 4, 5, 10, 11, 12, 13]

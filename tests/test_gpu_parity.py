@@ -12,11 +12,15 @@ import json
 import numpy as np
 import pytest
 
-from conftest import assert_close_scaled, load_golden
+from conftest import assert_close_scaled, load_golden, pure_rel_err
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-5
+RTOL = 1e-5     # the north_star bound; the assertions below sit at ~5x the worst error MEASURED on MI355X (round 2,
+                # gpurun_out/parity_errors.json, printed by every test session) wherever that is tighter
+# (post-state, observation, reward terms, reward) by kind of fixture; measured worst in the comments
+TOL_STEPS = (1.3e-6, 1.3e-6, 5e-6, 1e-6)      # G3 flights without events: 2.6e-7, 2.3e-7, 8.4e-7, 1.2e-7
+TOL_EVENTS = (5e-6, 5e-6, 1e-5, 1e-5)         # G4 / G10 with ground events: 1.0e-6, 1.0e-6, 2.9e-6, 3.2e-6
 # natural magnitude of the 7 reward terms with config.yaml coefficients: tracking ~0.1, thrust
 # penalty <= 0.01, eta = 0.1 per step; attitude (gamma = -10), goal (kappa = 10), final position /
 # velocity (up to max_v_f * w_v_f = 37.5) are O(1..10) quantities whose fp32 resolution is ~1e-6.
@@ -57,18 +61,22 @@ def _teacher_forced(torch, cfg, G, **kw):
     return env, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), infos
 
 
-def _check_against_golden(env, obs, rew, done, G, P, what):
+def _check_against_golden(env, obs, rew, done, G, P, what, tol=TOL_EVENTS):
     flags = env.flags.cpu().numpy()
     np.testing.assert_array_equal(done.astype(np.uint8), G["done"], err_msg=f"{what}: done mask")
     np.testing.assert_array_equal((flags & 2) >> 1, G["bounds"], err_msg=f"{what}: bounds flag")
     np.testing.assert_array_equal(flags & 1, (G["status"] == 1).astype(np.uint8), err_msg=f"{what}: ground-event status")
     post = env.get_state().cpu().numpy()
-    e_state = assert_close_scaled(post, G["post"], P.normalizer[None, :], RTOL, f"{what}: post-state")
-    e_obs = assert_close_scaled(obs, G["obs"], 1.0, RTOL, f"{what}: observation")
+    e_state = assert_close_scaled(post, G["post"], P.normalizer[None, :], tol[0], f"{what}: post-state")
+    e_obs = assert_close_scaled(obs, G["obs"], 1.0, tol[1], f"{what}: observation")
+    # "1e-5 relative" read literally, on every component that is not tiny against its natural scale
+    pr_state, pr_obs = pure_rel_err(post, G["post"], P.normalizer[None, :]), pure_rel_err(obs, G["obs"], 1.0)
+    assert pr_state < RTOL and pr_obs < RTOL, f"{what}: pure relative error state {pr_state:.2e} obs {pr_obs:.2e}"
     terms = env.terms[:7, : env.num_envs].t().cpu().numpy()
-    e_terms = assert_close_scaled(terms, G["terms"], TERM_SCALE, RTOL, f"{what}: reward terms")
-    e_rew = assert_close_scaled(rew, G["reward"], REWARD_SCALE, RTOL, f"{what}: reward")
-    print(f"[{what}] n={len(rew)} worst scaled err: state {e_state:.2e} obs {e_obs:.2e} terms {e_terms:.2e} reward {e_rew:.2e}")
+    e_terms = assert_close_scaled(terms, G["terms"], TERM_SCALE, tol[2], f"{what}: reward terms")
+    e_rew = assert_close_scaled(rew, G["reward"], REWARD_SCALE, tol[3], f"{what}: reward")
+    print(f"[{what}] n={len(rew)} worst scaled err: state {e_state:.2e} obs {e_obs:.2e} terms {e_terms:.2e} reward {e_rew:.2e}; "
+          f"pure relative: state {pr_state:.2e} obs {pr_obs:.2e}")
     return e_state, e_obs, e_terms, e_rew
 
 
@@ -98,7 +106,7 @@ def test_g2_rhs_known_answers(torch_cuda):
     got = dy[:, :n].t().cpu().numpy()
     # derivative scales: velocities ~1e2 m/s, accelerations ~1e1, qdot ~1, wdot ~1, mdot ~1e2
     scale = np.array([100, 100, 100, 10, 10, 10, 1, 1, 1, 1, 1, 1, 1, 100.0])
-    err = assert_close_scaled(got, g2["dy"], scale[None, :], RTOL, "RHS vs golden G2")
+    err = assert_close_scaled(got, g2["dy"], scale[None, :], 3.5e-6, "RHS vs golden G2")     # measured 6.5e-7
     print(f"[G2] worst scaled err {err:.2e}")
 
 
@@ -111,7 +119,7 @@ def test_g1_simulator_smoke_case(torch_cuda):
     state, status = sim.step(list(g1["u"]))
     assert status == int(g1["status"]) == 0
     scale = np.array([100, 100, 100, 5, 5, 5, 1, 1, 1, 1, 1e-2, 1e-2, 1e-2, 5e4])
-    assert_close_scaled(state, g1["state"], scale, RTOL, "G1 Simulator6DOF.step")
+    assert_close_scaled(state, g1["state"], scale, 1.1e-6, "G1 Simulator6DOF.step")     # measured 2.1e-7
     assert sim.t == 0.5 and len(sim.states) == 2 and len(sim.times) == 2
 
 
@@ -122,7 +130,7 @@ def test_env_step_teacher_forced_vs_reference(torch_cuda, cfg, P, fixture):
     ground-event masks bit-exact."""
     G = load_golden(fixture)
     env, obs, rew, done, _ = _teacher_forced(torch_cuda, cfg, G)
-    _check_against_golden(env, obs, rew, done, G, P, fixture)
+    _check_against_golden(env, obs, rew, done, G, P, fixture, tol=TOL_STEPS if fixture.startswith("g3") else TOL_EVENTS)
 
 
 def test_g5_reward_known_answers(torch_cuda, cfg, P):
@@ -180,7 +188,7 @@ def test_g3_free_running_episodes(torch_cuda, cfg, P):
         for e in np.nonzero(alive)[0]:
             i = starts[e] + k
             assert bool(done[e]) == bool(G["done"][i]), f"episode {e} step {k}: done {done[e]} vs {G['done'][i]}"
-            worst = max(worst, assert_close_scaled(st[e], G["post"][i], scale, 1e-4, f"episode {e} step {k} state"))
+            worst = max(worst, assert_close_scaled(st[e], G["post"][i], scale, 2e-5, f"episode {e} step {k} state"))     # free-running; measured 3.4e-6
     print(f"[G3 free-running] {n} episodes, {int(lens.sum())} steps, worst scaled state drift {worst:.2e}")
 
 
@@ -207,7 +215,7 @@ def test_g6_fixed_step_maps(torch_cuda, cfg, P, name, integ, h):
     np.testing.assert_array_equal((fl & 1).astype(bool), cross)
     assert np.abs(got[cross, 0]).max() < 1e-4
     got, want = got[~cross], want[~cross]
-    e = assert_close_scaled(got, want, P.normalizer[None, :], RTOL, f"G6 {name}")
+    e = assert_close_scaled(got, want, P.normalizer[None, :], 1e-6, f"G6 {name}")     # measured 1.9e-7
     print(f"[G6 {name}] worst scaled err {e:.2e}")
 
 
@@ -262,7 +270,7 @@ def test_velocity_shaping_vs_oracle(torch_cuda, cfg):
         o = onp.env_step(pre[i].astype(np.float32).astype(np.float64), float(np.float32(m0[i])), act[i], Pv, "rk4",
                          v0=float(np.float32(v0[i])))
         assert bool(done[i]) == o["done"]
-        assert_close_scaled(terms[i], o["terms"], TERM_SCALE, RTOL, f"velocity shaping terms {i}")
+        assert_close_scaled(terms[i], o["terms"], TERM_SCALE, 2e-6, f"velocity shaping terms {i}")     # measured 3.7e-7
 
 
 @pytest.mark.parametrize("tag", ["wp50", "wp400"])
@@ -285,7 +293,7 @@ def test_g10_velocity_shaping_vs_reference(torch_cuda, tag, integ):
     obs, rew, done, infos = env.step(torch.as_tensor(g["action"], device=env.device))
     torch.cuda.synchronize()
     e = _check_against_golden(env, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), g, Pv, f"G10 {tag} {integ}")
-    assert e[0] < 2e-6 and e[2] < RTOL
+    assert e[0] < 5e-6 and e[2] < 5e-6     # measured 9.1e-7 / 8.8e-7
     assert "vtarg_tracking" in infos[0]["rewards_dict"]
 
 
@@ -417,18 +425,18 @@ def test_wrapped_variant_vs_c_oracle(torch_cuda, cfg):
         np.testing.assert_array_equal(d.astype(np.uint8), rd, err_msg=f"step {k}: done")
         fl = env.flags.cpu().numpy()
         np.testing.assert_array_equal(fl, ref.flags, err_msg=f"step {k}: ground / bounds / truncated flags")
-        worst_rew = max(worst_rew, assert_close_scaled(rew.cpu().numpy(), rr, REWARD_SCALE, RTOL, f"step {k}: clipped reward"))
+        worst_rew = max(worst_rew, assert_close_scaled(rew.cpu().numpy(), rr, REWARD_SCALE, 6e-6, f"step {k}: clipped reward"))     # measured 1.3e-6
         assert float(rew.min()) >= -1.0 and float(rew.max()) <= 100.0
         n_clip += int(((rr == -1.0) | (rr == 100.0)).sum())
-        worst_obs = max(worst_obs, assert_close_scaled(obs.cpu().numpy(), ro[:, :13], 1.0, RTOL, f"step {k}: obs (13-wide, reset envs included)"))
+        worst_obs = max(worst_obs, assert_close_scaled(obs.cpu().numpy(), ro[:, :13], 1.0, 3e-6, f"step {k}: obs (13-wide, reset envs included)"))     # measured 6.0e-7
         # running counters of the live envs, Monitor's episode record and the terminal observation of the finished ones
         np.testing.assert_array_equal(env.ep_step.cpu().numpy(), ref.ep_step.astype(np.int32))
-        assert_close_scaled(env.ep_return.cpu().numpy(), ref.ep_return, 1.0, RTOL, f"step {k}: running return")
+        assert_close_scaled(env.ep_return.cpu().numpy(), ref.ep_return, 1.0, 1e-6, f"step {k}: running return")     # measured 1.3e-7
         if d.any():
             idx = np.nonzero(d)[0]
             np.testing.assert_array_equal(env.fin_length.cpu().numpy()[idx], ref.fin_length[idx].astype(np.int32))
-            assert_close_scaled(env.fin_return.cpu().numpy()[idx], ref.fin_return[idx], 1.0, RTOL, f"step {k}: episode return")
-            assert_close_scaled(env.final_obs.cpu().numpy()[idx], ref.final_obs[idx, :13], 1.0, RTOL, f"step {k}: terminal obs")
+            assert_close_scaled(env.fin_return.cpu().numpy()[idx], ref.fin_return[idx], 1.0, 6e-6, f"step {k}: episode return")     # measured 1.2e-6
+            assert_close_scaled(env.final_obs.cpu().numpy()[idx], ref.final_obs[idx, :13], 1.0, 1e-6, f"step {k}: terminal obs")     # measured 1.8e-7
             i = int(idx[0])
             info = infos[i]
             assert info["episode"]["l"] == int(ref.fin_length[i]) and info["TimeLimit.truncated"] == bool(ref.flags[i] & 4)
@@ -482,12 +490,12 @@ def test_g7_reward_wrappers_vs_reference(torch_cuda, cfg, name, kw):
     env.set_state(pre.astype(np.float32), m0=m0.astype(np.float32))
     obs, rew, done, infos = env.step(torch.as_tensor(act, device=env.device))
     np.testing.assert_array_equal(done.cpu().numpy(), g7[f"{name}_done"])
-    assert_close_scaled(rew.cpu().numpy(), g7[f"{name}_reward"], REWARD_SCALE, RTOL, f"G7 {name} reward")
+    assert_close_scaled(rew.cpu().numpy(), g7[f"{name}_reward"], REWARD_SCALE, 1e-6, f"G7 {name} reward")     # measured 1.8e-7
     terms = env.terms[:, :n].t().cpu().numpy()
     np.testing.assert_array_equal(terms[:, 7] != 0, g7[f"{name}_vatt"] != 0)
-    assert_close_scaled(terms[:, 7], g7[f"{name}_vatt"], 1.0, RTOL, f"G7 {name} vertical attitude term")
+    assert_close_scaled(terms[:, 7], g7[f"{name}_vatt"], 1.0, 1.3e-6, f"G7 {name} vertical attitude term")     # measured 2.4e-7
     if "reward_annealing" in kw:
-        assert_close_scaled(terms[:, 1], g7[f"{name}_tpen"], 1e-2, RTOL, f"G7 {name} thrust penalty")
+        assert_close_scaled(terms[:, 1], g7[f"{name}_tpen"], 1e-2, 1e-6, f"G7 {name} thrust penalty")     # measured 9.3e-8
         assert infos[0]["rewards_dict"]["eta"] == 0.0 and "vertical_attitude_reward" in infos[0]
 
 
@@ -505,11 +513,11 @@ def test_terminal_errors_montecarlo(torch_cuda, cfg):
     te = env.terminal_errors()
     assert len(te["env_index"]) == n
     post = G["post"][last]
-    assert_close_scaled(te["final_position_error"].cpu().numpy(), np.linalg.norm(post[:, 0:3], axis=1), 1.0, 1e-5, "position error")
-    assert_close_scaled(te["final_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 3:6], axis=1), 1.0, 1e-5, "velocity error")
+    assert_close_scaled(te["final_position_error"].cpu().numpy(), np.linalg.norm(post[:, 0:3], axis=1), 1.0, 1.3e-6, "position error")     # measured < 2.5e-7
+    assert_close_scaled(te["final_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 3:6], axis=1), 1.0, 1.3e-6, "velocity error")     # measured < 2.5e-7
     assert_close_scaled(te["attitude_error"].cpu().numpy(), 0.5 * np.rad2deg(np.arccos(post[:, 6])), 1.0, 1e-4, "attitude error")
-    assert_close_scaled(te["angular_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 10:13], axis=1), 0.1, 1e-5, "omega error")
-    assert_close_scaled(te["used mass"].cpu().numpy(), post[:, 13], 1.0, 1e-5, "terminal mass")
+    assert_close_scaled(te["angular_velocity_error"].cpu().numpy(), np.linalg.norm(post[:, 10:13], axis=1), 0.1, 1e-6, "omega error")     # measured 1.3e-7
+    assert_close_scaled(te["used mass"].cpu().numpy(), post[:, 13], 1.0, 1e-6, "terminal mass")     # measured 9.3e-8
 
 
 @pytest.mark.parametrize("fixture", ["g3_env_rollouts.npz", "g4_ground_events.npz"])
@@ -519,7 +527,7 @@ def test_rk45_adaptive_twin_vs_reference(torch_cuda, cfg, P, fixture):
     same bit-exact masks; additionally the per-step RHS-evaluation count is compared with scipy's nfev."""
     G = load_golden(fixture)
     env, obs, rew, done, _ = _teacher_forced(torch_cuda, cfg, G, integrator="rk45", record_nfev=True)
-    _check_against_golden(env, obs, rew, done, G, P, fixture + " rk45")
+    _check_against_golden(env, obs, rew, done, G, P, fixture + " rk45", tol=TOL_STEPS if fixture.startswith("g3") else TOL_EVENTS)
     nfev = env.nfev.cpu().numpy().astype(int)
     same = float((nfev == G["nfev"]).mean())
     print(f"[{fixture} rk45] nfev identical to scipy on {100 * same:.1f}% of the steps "
@@ -536,7 +544,7 @@ def test_rk45_simulator_smoke_case_single_step(torch_cuda):
     state, status = sim.step(list(g1["u"]))
     assert status == 0
     scale = np.array([100, 100, 100, 5, 5, 5, 1, 1, 1, 1, 1e-2, 1e-2, 1e-2, 5e4])
-    assert_close_scaled(state, g1["state"], scale, RTOL, "G1 Simulator6DOF.step rk45")
+    assert_close_scaled(state, g1["state"], scale, 1e-6, "G1 Simulator6DOF.step rk45")     # measured 1.0e-7
 
 
 def test_edge_cases_nan_unclipped_actions_substeps(torch_cuda, cfg, P):
@@ -562,8 +570,8 @@ def test_edge_cases_nan_unclipped_actions_substeps(torch_cuda, cfg, P):
     for i in range(0, n, 3):
         o = onp.env_step(pre[i].astype(np.float64), float(m0[i]), act[i], P, "rk4")
         assert bool(done[i]) == o["done"]
-        assert_close_scaled(post[i], o["post"], P.normalizer, RTOL, f"unclipped action env {i}")
-        assert_close_scaled(float(rew[i]), o["reward"], REWARD_SCALE, RTOL, f"unclipped action reward {i}")
+        assert_close_scaled(post[i], o["post"], P.normalizer, 1e-6, f"unclipped action env {i}")     # measured 1.3e-7
+        assert_close_scaled(float(rew[i]), o["reward"], REWARD_SCALE, 1e-6, f"unclipped action reward {i}")     # measured 7.1e-8
 
     bad = pre.copy()
     bad[0, 0] = np.nan
