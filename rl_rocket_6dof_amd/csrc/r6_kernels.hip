@@ -48,6 +48,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef R6_PRIO_REMAINING
 #define R6_PRIO_REMAINING 0     // A/B switch: wave priority from the tiles left (1: measured 0.4-1.6 us slower) or from the tiles done (0)
 #endif
+#ifndef R6_SWEEP_DEFAULT
+#define R6_SWEEP_DEFAULT -1     // odd steps on the resident grid: 0 = as even steps, 1 = every wave walks its own list backwards, 2 = whole range mirrored, -1 = per integrator
+#endif
 #ifndef R6_ACT_LDS
 #define R6_ACT_LDS 0            // A/B switch: action edge staged through LDS (1) or one 12-byte load per lane (0)
 #endif
@@ -207,7 +210,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset,
-                                                      const uint32_t even_share_q16) {
+                                                      const uint32_t even_share_q16, const uint32_t sweep) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
     // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
@@ -473,19 +476,40 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     // the RK4 instances lose with it (38.1 -> 38.7 claimed ahead, 40.0 claimed late: a wave that takes a tile late
     // in the launch finishes it alone) and keep their fixed per-wave lists.
     constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;
-    int wg_j = wave, wg_jn = -1;
     const int64_t wg_first = t_first - wave;
+    // Order of a wave's (workgroup's) tile list.  sweep bit 0 (odd steps on the persistent grid): the list is walked
+    // backwards, so that the tile a wave wrote LAST in the previous launch is the one it reads FIRST in this one.
+    // Workgroup i always runs on XCD i % 8, so those rows are still in that XCD's L2 (4 MB; the state rows of the last
+    // tiles of an XCD's 640 waves are 2.4 MB): the first loads of the launch -- the ramp during which no SIMD has
+    // anything to compute -- come from L2 instead of the fabric.  sweep bit 1 (odd steps on the big dispatcher-balanced
+    // grid, N >= 3 M envs): the whole tile range is mirrored instead, what the previous step wrote last is read first while
+    // it is still in the 256 MB Infinity Cache (N = 2^22: 208 -> 159 us per step).
+    const bool rev = (sweep & 1u) != 0u;
+    const int n_my = t_first < pool_tiles ? (int)((pool_tiles - 1 - t_first) / nw) + 1 : 0;   // fixed list: tiles of this wave
+    int n_wg = 0;                                                                               // kWgDyn: tiles of this workgroup
+    if constexpr (kWgDyn) {
 #pragma unroll 1
-    for (int64_t tp = t_first; tp < pool_tiles; tp = kWgDyn ? wg_first + (int64_t)(wg_j / kWaves) * nw + (wg_j % kWaves) : tp + nw) {
+        for (int64_t g0 = wg_first; g0 < pool_tiles; g0 += nw) n_wg += (pool_tiles - g0 < kWaves) ? (int)(pool_tiles - g0) : kWaves;
+    }
+    auto list_tile = [&](int pos) __attribute__((always_inline)) -> int64_t {
+        if constexpr (kWgDyn) {
+            const int jj = rev ? n_wg - 1 - pos : pos;
+            return wg_first + (int64_t)(jj / kWaves) * nw + (jj % kWaves);
+        } else {
+            return t_first + (int64_t)(rev ? n_my - 1 - pos : pos) * nw;
+        }
+    };
+    const int n_pos = kWgDyn ? n_wg : n_my;
+    int wg_jn = -1;
+#pragma unroll 1
+    for (int pos = kWgDyn ? wave : 0; pos < n_pos;) {
+        const int64_t tp = list_tile(pos);
         const int64_t ts = pool_base + tp;
-        // Odd steps walk the tiles backwards: what the previous step wrote last is read first, while it is still
-        // in the 256 MB Infinity Cache.  Irrelevant at N = 2^20 (the whole working set fits), 208 -> 159 us per
-        // step at N = 2^22 (800 MB working set: 3.8 -> 5.0 TB/s algorithmic).
-        const int64_t t = (step_index & 1) ? (n_tiles - 1 - ts) : ts;
+        const int64_t t = (sweep & 2u) ? (n_tiles - 1 - ts) : ts;
 #if R6_PRIO_REMAINING
         {   // priority = tiles this wave still has to do after this one (capped at 3): a wave that owns one tile more
             // than its neighbours runs its first tile ahead of them instead of its last one behind them
-            const int64_t left = (pool_tiles - 1 - tp) / nw;
+            const int64_t left = n_pos - 1 - pos;
             if (left >= 3) __builtin_amdgcn_s_setprio(3);
             else if (left == 2) __builtin_amdgcn_s_setprio(2);
             else if (left == 1) __builtin_amdgcn_s_setprio(1);
@@ -511,16 +535,16 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
                 // before this tile is computed: 37.0 -> 34.7 us.  The same costs the RK4 instance 1.2 us.
                 if (have_nxt) cur = nxt;
                 else load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
-                int64_t tpn = tp + nw;
+                int pos_n = pos + 1;
                 if constexpr (kWgDyn) {   // the tile after this one is claimed now, so that its inputs can be requested
                     int nj = 0;
                     if (lane == 0) nj = atomicAdd(&wg_next, 1);
                     wg_jn = __builtin_amdgcn_readfirstlane(nj);
-                    tpn = wg_first + (int64_t)(wg_jn / kWaves) * nw + (wg_jn % kWaves);
+                    pos_n = wg_jn;
                 }
-                const int64_t tsn = pool_base + tpn;
-                const int64_t tn = (step_index & 1) ? (n_tiles - 1 - tsn) : tsn;
-                have_nxt = tpn < pool_tiles && tn < n_full;
+                const int64_t tsn = pool_base + list_tile(pos_n < n_pos ? pos_n : pos);
+                const int64_t tn = (sweep & 2u) ? (n_tiles - 1 - tsn) : tsn;
+                have_nxt = pos_n < n_pos && tn < n_full;
                 if (have_nxt) load_tile<SHAPING, true>(b, has_ep, tn * 64, lane, nxt);
             } else {
                 load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
@@ -560,13 +584,15 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         }
         if constexpr (kWgDyn) {
             if (wg_jn >= 0) {   // claimed ahead by the prefetch
-                wg_j = wg_jn;
+                pos = wg_jn;
                 wg_jn = -1;
             } else {            // partial tile / no prefetch issued: claim now (lane 0 asks, the wave reads the answer as a scalar)
                 int nj = 0;
                 if (lane == 0) nj = atomicAdd(&wg_next, 1);
-                wg_j = __builtin_amdgcn_readfirstlane(nj);
+                pos = __builtin_amdgcn_readfirstlane(nj);
             }
+        } else {
+            ++pos;
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1000,7 +1026,18 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     // XCD-aware split (see step_kernel): only for the persistent grid, where every wave walks several tiles
     uint32_t even_share = 0;
     if (blocks == cap && (blocks % 8) == 0 && n_tiles >= 2 * blocks * r6::kWaves) even_share = even_xcd_share_q16(INTEG);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share);
+    // Order of the tiles on odd steps (see step_kernel).  Measured in one process at N = 2^20 / 2^21 / 2^22 (us per step;
+    // as even steps | every wave's list backwards | whole range mirrored): RK4 38.0 | 39.4 | 38.8, 85.2 | 90.8 | 90.1,
+    // 154 | 159 | 162 (the last size runs the dispatcher-balanced grid, where only "mirrored" exists: its three numbers are
+    // the same code and show the +-3 % between allocations); Euler 38.0 | 36.8 | 36.5, 84 | 94 | 94, 160 | 150 | 154.
+    // So: the RK4 / RK45 instances keep one order on the resident grid, the Euler instances walk their lists backwards,
+    // and the dispatcher-balanced grid mirrors the range (N = 2^23: 328 -> 291 us with the streaming stores, round 1).
+    // R6_SWEEP=0|1|2 overrides the resident-grid choice.
+    static const int sweep_env = [] { const char* e = std::getenv("R6_SWEEP"); return e ? std::atoi(e) : R6_SWEEP_DEFAULT; }();
+    const int sweep_mode = sweep_env >= 0 ? sweep_env : (INTEG == R6_EULER ? 1 : 0);
+    uint32_t sweep = 0;
+    if (step & 1) sweep = (blocks > cap || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep);
 }
 
 template <int INTEG, int SHAPING, int OD>
