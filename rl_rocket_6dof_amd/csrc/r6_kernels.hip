@@ -477,13 +477,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     // in the launch finishes it alone) and keep their fixed per-wave lists.
     constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;
     const int64_t wg_first = t_first - wave;
-    // Order of a wave's (workgroup's) tile list.  sweep bit 0 (odd steps on the persistent grid): the list is walked
-    // backwards, so that the tile a wave wrote LAST in the previous launch is the one it reads FIRST in this one.
-    // Workgroup i always runs on XCD i % 8, so those rows are still in that XCD's L2 (4 MB; the state rows of the last
-    // tiles of an XCD's 640 waves are 2.4 MB): the first loads of the launch -- the ramp during which no SIMD has
-    // anything to compute -- come from L2 instead of the fabric.  sweep bit 1 (odd steps on the big dispatcher-balanced
-    // grid, N >= 3 M envs): the whole tile range is mirrored instead, what the previous step wrote last is read first while
-    // it is still in the 256 MB Infinity Cache (N = 2^22: 208 -> 159 us per step).
+    // Order of a wave's (workgroup's) tile list, chosen per launch by the host (launch_step_inst has the numbers).
+    // sweep bit 0: the list is walked backwards -- the tile a wave wrote last in the previous launch is the one it reads
+    // first in this one (workgroup i always runs on XCD i % 8, so those rows were last touched through the same L2).
+    // It pays for the memory-bound Euler instances only; the RK4 instances measure 0.8-1.5 us FASTER with one fixed
+    // order at N = 2^20 (their first loads wait 2.5 us after a forward launch and 3.3 us after a reversed one).
+    // sweep bit 1 (dispatcher-balanced grid, N >= 3 M envs): the whole tile range is mirrored instead, what the previous
+    // step wrote last is read first while it is still in the 256 MB Infinity Cache.
     const bool rev = (sweep & 1u) != 0u;
     const int n_my = t_first < pool_tiles ? (int)((pool_tiles - 1 - t_first) / nw) + 1 : 0;   // fixed list: tiles of this wave
     int n_wg = 0;                                                                               // kWgDyn: tiles of this workgroup
