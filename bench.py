@@ -316,16 +316,16 @@ def main(argv=None):
         # the one collective of the design (episode summaries) inside a second, short timed loop:
         # BASELINE configs[4]'s per-rollout exchange
         gsteps = max(args.gather_every, min(args.steps, 10 * args.gather_every) // args.gather_every * args.gather_every)
-        gathers = []
+        gathers = []     # per-rank tables stay on the device: the all-gather is stream-ordered, the loop never drains the GPU
         wall_g, _ = timed_loop(env, pool, gsteps, args.k, barrier, stream, torch,
-                               every=(args.gather_every, lambda: gathers.append(r6dist.gather_episode_stats(env.episode_stats(), device=dev)[0])))
+                               every=(args.gather_every, lambda: gathers.append(r6dist.gather_episode_stats_device(env.episode_stats_tensor()))))
         redg = r6dist.reduce_bench_times(wall_g, 0.0, device=dev)
         extras["rccl"] = {"backend": backend, "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
                           "kernel_us_min": red["kernel_ms_min"] * 1e3, "kernel_us_max": red["kernel_ms_max"] * 1e3,
                           "wall_s_min": red["wall_min"], "wall_s_max": red["wall_max"],
                           "with_rollout_gather": {"gather_every": args.gather_every, "steps": gsteps, "gathers": len(gathers),
                                                   "value": n * world * gsteps / redg["wall_max"], "unit": "env-steps/s",
-                                                  "episodes_seen": gathers[-1]["episodes"] if gathers else 0.0}}
+                                                  "episodes_seen": float(sum(float(t[:, 0].sum()) for t in gathers))}}
 
     if rank == 0:
         dt = args.dt or cfg["timestep"]

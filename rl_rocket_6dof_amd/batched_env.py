@@ -368,6 +368,16 @@ class BatchedRocket6DOF(VecEnv):
             out["used mass"] = st[:, 13]
         return out
 
+    def episode_stats_tensor(self, clear: bool = True) -> torch.Tensor:
+        """The sums of ``episode_stats`` as a float64 device tensor [NUM_STATS], without a host synchronisation
+        (stream-ordered: one reduction kernel and, with ``clear``, one fill)."""
+        if self.stats is None:
+            raise RuntimeError("episode tracking is disabled (track_episodes=False)")
+        s = self.stats.sum(0)
+        if clear:
+            self.stats.zero_()
+        return s
+
     def episode_stats(self, clear: bool = True) -> dict:
         """Sums over the episodes finished since the last clear (per-workgroup partials reduced in
         float64 on the host)."""

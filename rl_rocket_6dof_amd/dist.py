@@ -61,6 +61,23 @@ def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str
     return {k: float(tot[i]) for i, k in enumerate(STAT_NAMES)}, table
 
 
+def gather_episode_stats_device(vec: torch.Tensor) -> torch.Tensor:
+    """All-gather of a rank's episode summary given as a float64 DEVICE tensor [NUM_STATS]
+    (``BatchedRocket6DOF.episode_stats_tensor``): returns the per-rank table [world, NUM_STATS] on the same device.
+    Under RCCL (backend nccl) nothing touches the host -- the collective is stream-ordered behind the kernels that
+    produced the sums, so a rollout loop can issue it without draining the GPU; gloo goes through the host."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return vec.reshape(1, -1)
+    world = dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world, vec.numel()), dtype=vec.dtype, device=vec.device)
+        dist.all_gather_into_tensor(out, vec.contiguous())
+        return out
+    rows = [torch.empty(vec.numel(), dtype=vec.dtype) for _ in range(world)]
+    dist.all_gather(rows, vec.cpu())
+    return torch.stack(rows).to(vec.device)
+
+
 def reduce_bench_times(wall_s: float, kernel_ms: float, device=None) -> Dict[str, object]:
     """Min / max over ranks of a rank's wall time and per-step kernel time (bench.py: the job's time is the slowest
     rank's), plus the device index every rank ran on.  One all-gather of three float64 per rank: through the device for

@@ -50,6 +50,9 @@ def _worker(rank, world, port, total, q):
         stats["length_sum"] += (pre_len + 1)[d].sum()
     tot, table = r6dist.gather_episode_stats(stats)
     assert table.shape == (world, len(STAT_NAMES))
+    # the tensor form used inside rollout loops (device tensors under RCCL; plain CPU tensors here)
+    dev_table = r6dist.gather_episode_stats_device(torch.tensor([stats[k] for k in STAT_NAMES], dtype=torch.float64))
+    assert dev_table.shape == (world, len(STAT_NAMES)) and torch.equal(dev_table, table)
     assert abs(table[rank, 0].item() - stats["episodes"]) < 0.5
     q.put((rank, off, cnt, env.state.copy(), tot, r6dist.summarize(tot)))
     dist.barrier()
