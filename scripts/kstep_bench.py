@@ -11,12 +11,13 @@ ap.add_argument("--k", type=int, nargs="+", default=[1, 4, 16, 64])
 ap.add_argument("--integrator", default="euler")
 ap.add_argument("--dt", type=float, default=0.04)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--lib", default=None)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = default_env_config()
 for n in args.n:
     env = BatchedRocket6DOF(n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, record_flags=False,
-                            track_episodes=False, seed=42)
+                            track_episodes=False, seed=42, lib_path=args.lib)
     env.reset()
     gen = torch.Generator(device=dev).manual_seed(1)
     kmax = max(args.k)
