@@ -163,9 +163,9 @@ def derive_spec(env_config: dict) -> EnvSpec:
     omega_max = MAX_THRUST * math.sin(MAX_GIMBAL) * lever_arm / inertia * float(t_free_fall) / 5.0
     v_max = float(f32(2 * 9.81) * t_free_fall)
     normalizer = np.maximum(
-        np.array([1.2 * abs(float(icm[0])), 1.5 * abs(float(icm[1])), 1.5 * abs(float(icm[2])),
+        np.array([float(f32(1.2) * abs(icm[0])), float(f32(1.5) * abs(icm[1])), float(f32(1.5) * abs(icm[2])),   # float32 products, like t_free_fall
                   v_max, v_max, v_max, 1.1, 1.1, 1.1, 1.1, omega_max, omega_max, omega_max,
-                  float(icm[13]) + float(icr[13])]), 1.0)
+                  float(icm[13] + icr[13])]), 1.0)
     hi = (0.9 * np.maximum(normalizer[0:3], 200)).astype(np.float32)
     lo = np.concatenate([[-30.0], -0.9 * np.maximum(normalizer[1:3], 200)]).astype(np.float32)
     shaping = env_config.get("reward_shaping_type", "acceleration")

@@ -29,6 +29,10 @@ What each file pins (reference file:line):
                    _compute_vtarg, two waypoints on either side of the flight, v0 = |IC velocity| recorded):
                    random-action episodes from the config's IC distribution plus low-altitude ones that end
                    in ground events   (--only g10)
+  g11_other_configs   the reference env built from env_configs OTHER than config.yaml (timestep 0.05 / 0.2, moved IC and
+                   ICRange, every reward coefficient changed incl. a non-zero w_r_f, tighter trajectory / landing limits, a
+                   different landing radius and velocity): pins the host-side digestion of env_config (rocket_env.py:22-178)
+                   and the parameters' way through the kernel beyond the one shipped configuration   (--only g11)
   g9_shipped_policy_in_reference   the policy trained on the HIP env (examples/policies/) flown in the REFERENCE
                    env: 16 episodes, terminal states, landing flags   (--only g9)
 """
@@ -359,7 +363,71 @@ def gen_g10():
                         meta=_meta({"reward_terms": ["vtarg_tracking"] + TERMS[1:]}), **out)
 
 
+def gen_g11():
+    """Rocket6DOF built from env_configs other than config.yaml."""
+    import copy
+
+    Sim, Env, cfg = load_reference()
+    sim_module = sys.modules["my_environment.utils.simulator"]
+    spy = _IvpSpy(sim_module)
+    variants = {}
+    a = copy.deepcopy(cfg)
+    a["timestep"] = 0.05
+    a["IC"] = [900.0, 400.0, -60.0, -60.0, -40.0, 8.0, 0.9239, 0.0, 0.3827, 0.0, 0.0, 0.0, 0.0, 36.0e3]
+    a["ICRange"] = [100.0, 100.0, 40.0, 20.0, 20.0, 6.0, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1, 4.0e3]
+    a["reward_coeff"].update(alfa=-0.03, beta=-3.0e-8, eta=0.05, gamma=-4.0, kappa=25.0, w_r_f=0.2, w_v_f=1.5, max_r_f=60.0, max_v_f=30.0)
+    a["trajectory_limits"]["attitude_limit"] = [60, 70, 360]
+    a["landing_params"].update(landing_radius=20, maximum_velocity=6, landing_attitude_limit=[6, 12, 360])
+    variants["a"] = a
+    b = copy.deepcopy(cfg)
+    b["timestep"] = 0.2
+    b["IC"] = [1500.0, -300.0, 120.0, -70.0, 30.0, -12.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 39.0e3]
+    b["ICRange"] = [200.0, 300.0, 100.0, 30.0, 30.0, 10.0, 0.2, 0.2, 0.2, 0.2, 0.05, 0.05, 0.05, 2.0e3]
+    b["reward_coeff"].update(alfa=-0.002, beta=-5.0e-9, eta=0.2, gamma=-20.0, kappa=5.0, w_r_f=0.0, w_v_f=0.3, max_r_f=150.0, max_v_f=80.0)
+    b["trajectory_limits"]["attitude_limit"] = [45, 45, 360]
+    b["landing_params"].update(landing_radius=50, maximum_velocity=15, landing_attitude_limit=[20, 20, 360])
+    variants["b"] = b
+    out = {}
+    for tag, vcfg in variants.items():
+        env = Env(**vcfg)
+        rng = np.random.RandomState(1100 + ord(tag))
+        eps, x0s = [], []
+        for k in range(3):       # flights from this config's own IC distribution
+            acts = (0.6 * rng.uniform(-1, 1, (400, 3)) + np.array([0.0, 0.0, 0.2 * k])).astype(np.float32)
+            x0, recs = _run_episode(env, spy, acts, max_steps=120)
+            eps.append(recs)
+            x0s.append(x0)
+        for k in range(30):      # low-altitude descents: events, goal conditions with the changed landing limits
+            icv = np.zeros(14)
+            icv[0] = rng.uniform(0.4, 40.0)
+            icv[1:3] = rng.uniform(-45, 45, 2)
+            icv[3] = rng.uniform(-25, -1.5)
+            icv[4:6] = rng.uniform(-6, 6, 2)
+            icv[6:10] = _quat_from_axis_angle([0.0, rng.normal(), rng.normal() + 1e-9], rng.uniform(0, 0.45))
+            icv[10:13] = rng.uniform(-0.3, 0.3, 3)
+            icv[13] = rng.uniform(30e3, 41e3)
+            acts = rng.uniform(-1, 1, (200, 3)).astype(np.float32)
+            acts[:, 2] = rng.uniform(-0.7, 0.3, 200)
+            x0, recs = _run_episode(env, spy, acts, ic=icv)
+            eps.append(recs)
+            x0s.append(x0)
+        g = _pack(eps)
+        g["x0"] = np.array(x0s)
+        g["normalizer"] = np.asarray(env.state_normalizer, float)
+        g["bounds_low"] = np.asarray(env.position_bounds_space.low, float)
+        g["bounds_high"] = np.asarray(env.position_bounds_space.high, float)
+        for k_, v in g.items():
+            out[f"{tag}_{k_}"] = v
+        out[f"config_{tag}"] = np.array(json.dumps(vcfg))
+        print("G11", tag, "dt", vcfg["timestep"], "steps", len(g["reward"]), "ground events", int((g["status"] == 1).sum()), "done", int(g["done"].sum()),
+              "goal", int((g["terms"][:, 4] != 0).sum()), "attitude penalty", int((g["terms"][:, 3] != 0).sum()), "bounds", int(g["bounds"].sum()))
+    np.savez_compressed(os.path.join(HERE, "g11_other_configs.npz"), meta=_meta(), **out)
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g11":
+        gen_g11()
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g10":
         gen_g10()
         return

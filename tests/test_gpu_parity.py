@@ -297,6 +297,31 @@ def test_g10_velocity_shaping_vs_reference(torch_cuda, tag, integ):
     assert "vtarg_tracking" in infos[0]["rewards_dict"]
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("integ", ["rk4", "rk45"])
+def test_g11_other_configs_vs_reference(torch_cuda, tag, integ):
+    """env_configs other than config.yaml -- timestep 0.05 / 0.2 (two RK4 sub-steps by the kernel's rule), moved IC /
+    ICRange, every reward coefficient incl. a non-zero w_r_f, tighter attitude limits, other landing radius / velocity /
+    attitude limits -- through `make_params` and the kernel, against the REFERENCE's own runs (golden G11)."""
+    torch = torch_cuda
+    from oracle import oracle_np as onp
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    G = load_golden("g11_other_configs.npz")
+    vcfg = json.loads(str(G[f"config_{tag}"]))
+    Pv = onp.OracleParams.from_config(vcfg)
+    g = {k[len(tag) + 1:]: G[k] for k in G.files if k.startswith(tag + "_")}
+    n = len(g["reward"])
+    env = BatchedRocket6DOF(n, vcfg, auto_reset=False, record_terms=True, integrator=integ)
+    assert abs(env.timestep - vcfg["timestep"]) < 1e-7 and (integ == "rk45" or env.params.n_substeps == (1 if tag == "a" else 2))
+    np.testing.assert_allclose(env.state_normalizer, g["normalizer"], rtol=1e-6)
+    env.set_state(g["pre"].astype(np.float32), m0=g["m0"].astype(np.float32))
+    obs, rew, done, _ = env.step(torch.as_tensor(g["action"], device=env.device))
+    torch.cuda.synchronize()
+    e = _check_against_golden(env, obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), g, Pv, f"G11 {tag} {integ}")
+    assert int((g["terms"][:, 3] != 0).sum()) > 50, "the changed attitude limit is exercised"
+
+
 def test_reset_matches_oracle_stream(torch_cuda, cfg, P):
     """Rocket6DOF.reset (rocket_env.py:180-199): the Philox initial-condition stream is bit-identical
     to the oracle's for the 10 plain components; the quaternion (normalised in fp32) to 1 ulp."""

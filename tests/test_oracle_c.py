@@ -158,3 +158,25 @@ def test_g10_velocity_shaping_vs_reference(tag):
     assert_close_scaled(env.state, g["post"], Pv.normalizer[None, :], 2e-6, "C post-state vs reference (G10)")
     assert_close_scaled(env.terms, g["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference (G10)")
     assert_close_scaled(rew, g["reward"], 1e-1, 2e-5, "C reward vs reference (G10)")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g11_other_configs_vs_reference(tag):
+    """The C restatement built from env_configs other than config.yaml against the reference's own runs (golden G11)."""
+    from rl_rocket_6dof_amd.params import auto_substeps
+
+    G = load_golden("g11_other_configs.npz")
+    vcfg = json.loads(str(G[f"config_{tag}"]))
+    Pv = onp.OracleParams.from_config(vcfg)
+    g = {k[len(tag) + 1:]: G[k] for k in G.files if k.startswith(tag + "_")}
+    n = len(g["reward"])
+    env = oc.BatchOracle(n, vcfg, n_substeps=auto_substeps(vcfg["timestep"]))
+    env.set_state(g["pre"], m0=g["m0"])
+    obs, rew, done = env.step(g["action"])
+    np.testing.assert_array_equal(done, g["done"])
+    np.testing.assert_array_equal((env.flags & 2) >> 1, g["bounds"])
+    np.testing.assert_array_equal(env.flags & 1, (g["status"] == 1).astype(np.uint8))
+    assert_close_scaled(env.state, g["post"], Pv.normalizer[None, :], 2e-6, "C post-state vs reference (G11)")
+    assert_close_scaled(obs, g["obs"], 1.0, 2e-6, "C obs vs reference (G11)")
+    assert_close_scaled(env.terms, g["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference (G11)")
+    assert_close_scaled(rew, g["reward"], 1e-1, 2e-5, "C reward vs reference (G11)")

@@ -228,3 +228,32 @@ def test_g10_velocity_shaping(tag):
             assert_close_scaled(out["post"], g["post"][i], _scale(Pv), rs, f"G10 {tag} {integ} post {i}")
             assert_close_scaled(out["terms"], g["terms"][i], 1e-2, rr, f"G10 {tag} {integ} terms {i}")
             assert_close_scaled(out["reward"], g["reward"][i], 1e-1, rr, f"G10 {tag} {integ} reward {i}")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g11_other_configs(tag):
+    """env_configs other than config.yaml (timestep 0.05 / 0.2, moved IC / ICRange, every reward coefficient, attitude and
+    landing limits changed), recorded from the reference: derived quantities, then the oracle's adaptive flavour to
+    round-off and its fixed-RK4 flavour (sub-steps of at most 0.1 s, the kernel's rule) to the integrator contract."""
+    import json
+
+    from conftest import load_golden
+    from rl_rocket_6dof_amd.params import auto_substeps
+
+    G = load_golden("g11_other_configs.npz")
+    vcfg = json.loads(str(G[f"config_{tag}"]))
+    Pv = onp.OracleParams.from_config(vcfg)
+    g = {k[len(tag) + 1:]: G[k] for k in G.files if k.startswith(tag + "_")}
+    np.testing.assert_allclose(Pv.normalizer, g["normalizer"], rtol=1e-12)
+    np.testing.assert_array_equal(Pv.bounds_low.astype(np.float64), g["bounds_low"])
+    np.testing.assert_array_equal(Pv.bounds_high.astype(np.float64), g["bounds_high"])
+    n = len(g["reward"])
+    nsub = auto_substeps(vcfg["timestep"])
+    assert nsub == (1 if tag == "a" else 2)
+    for integ, rs, rr, stride, ns in (("adaptive", 2e-8, 5e-6, 5, 1), ("rk4", 2e-6, 2e-5, 1, nsub)):
+        for i in range(0, n, stride):
+            out = onp.env_step(g["pre"][i], float(g["m0"][i]), g["action"][i], Pv, integ, ns)
+            assert out["done"] == bool(g["done"][i]) and out["bounds"] == bool(g["bounds"][i]) and out["status"] == int(g["status"][i])
+            assert_close_scaled(out["post"], g["post"][i], _scale(Pv), rs, f"G11 {tag} {integ} post {i}")
+            assert_close_scaled(out["terms"], g["terms"][i], 1e-2, rr, f"G11 {tag} {integ} terms {i}")
+            assert_close_scaled(out["reward"], g["reward"][i], 1e-1, rr, f"G11 {tag} {integ} reward {i}")
