@@ -125,10 +125,6 @@ struct Rot {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
 
-#ifndef R6_OPT_UNITQ
-#define R6_OPT_UNITQ 1   // A/B switch: the reward's rotation matrix skips 1/|q|^2 (the step has just renormalised q)
-#endif
-
 template <bool UNIT = false>
 __device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
     // UNIT: the caller guarantees |q| = 1 to fp32 round-off (sim:97 renormalises after every step), s = 2 / |q|^2 = 2
@@ -151,10 +147,6 @@ __device__ __forceinline__ Rot rotmat(float q0, float q1, float q2, float q3) {
     return R;
 }
 
-#ifndef R6_OPT_ROT
-#define R6_OPT_ROT 1   // 1: rotate the two vectors with the quaternion directly; 0: through the 3x3 matrix (A/B switch)
-#endif
-
 // sim:106-143 -- the force / torque half of the RHS: dv[3] = d(v)/dt, dw[2] = d(omega_y, omega_z)/dt
 // (d(omega_x)/dt == 0, see below); `im` = 1 / mass at this time.
 //
@@ -168,7 +160,6 @@ __device__ __forceinline__ void rhs_dyn(const float (&y)[kDyn], float im, const 
     const float speed = fsqrt(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
     // aero (sim:216-219): A_B = -k rho |v| R^T v ; rotated back: A_I = -k rho |v| v
     const float ca = -kAeroK * density(y[0]) * speed;
-#if R6_OPT_ROT
     const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
     const float n2 = fmaf(q0, q0, fmaf(q1, q1, fmaf(q2, q2, q3 * q3)));
     const float s = 2.0f * frcp(n2);
@@ -191,19 +182,6 @@ __device__ __forceinline__ void rhs_dyn(const float (&y)[kDyn], float im, const 
     dv[0] = fmaf(fmaf(ca, vx, tix), im, -(float)kG0);
     dv[1] = fmaf(ca, vy, tiy) * im;
     dv[2] = fmaf(ca, vz, tiz) * im;
-#else
-    const Rot R = rotmat(y[6], y[7], y[8], y[9]);
-    const float aby = ca * fmaf(R.r01, vx, fmaf(R.r11, vy, R.r21 * vz));  // body-y aero force
-    const float abz = ca * fmaf(R.r02, vx, fmaf(R.r12, vy, R.r22 * vz));  // body-z aero force
-
-    // translational (sim:124-130, :156-165): F_I = R T_B + A_I
-    const float fx = fmaf(R.r00, c.tbx, fmaf(R.r01, c.tby, fmaf(R.r02, c.tbz, ca * vx)));
-    const float fy = fmaf(R.r10, c.tbx, fmaf(R.r11, c.tby, fmaf(R.r12, c.tbz, ca * vy)));
-    const float fz = fmaf(R.r20, c.tbx, fmaf(R.r21, c.tby, fmaf(R.r22, c.tbz, ca * vz)));
-    dv[0] = fmaf(fx, im, -(float)kG0);
-    dv[1] = fy * im;
-    dv[2] = fz * im;
-#endif
 
     // rotational (sim:137, :232-244): tau = r_T x T_B + r_cp x A_B with r = [rx,0,0]
     //   -> tau = (0, -rT*tbz - rcp*abz, rT*tby + rcp*aby);  J = diag(Jx,Jt,Jt):
@@ -732,7 +710,7 @@ __device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[
     RewardOut o;
     const float rx = y[0], ry = y[1], rz = y[2];
     const float vx = y[3], vy = y[4], vz = y[5];
-    const Rot R = rotmat<R6_OPT_UNITQ != 0>(y[6], y[7], y[8], y[9]);   // post-step attitude: renormalised by integrate()
+    const Rot R = rotmat<true>(y[6], y[7], y[8], y[9]);   // post-step attitude: renormalised by integrate()
     const float vv = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
     const float rr = fmaf(rx, rx, fmaf(ry, ry, rz * rz));
     const float vn = fsqrt(vv);

@@ -45,9 +45,6 @@ __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) 
 //     SGPRs across the loop.
 // -------------------------------------------------------------------------------------------------
 constexpr int kWaves = kBlock / 64;
-#ifndef R6_PRIO_REMAINING
-#define R6_PRIO_REMAINING 0     // A/B switch: wave priority from the tiles left (1: measured 0.4-1.6 us slower) or from the tiles done (0)
-#endif
 #ifndef R6_SWEEP_DEFAULT
 #define R6_SWEEP_DEFAULT -1     // odd steps on the resident grid: 0 = as even steps, 1 = every wave walks its own list backwards, 2 = whole range mirrored, -1 = per integrator
 #endif
@@ -195,9 +192,6 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
     }
 }
 
-#ifndef R6_DISABLE_ONE
-#define R6_DISABLE_ONE 0   // A/B switch (scripts/build_variant.sh): 1 = always the general sub-step loop
-#endif
 #ifndef R6_RK4_WAVES
 #define R6_RK4_WAVES 5
 #endif
@@ -506,21 +500,10 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         const int64_t tp = list_tile(pos);
         const int64_t ts = pool_base + tp;
         const int64_t t = (sweep & 2u) ? (n_tiles - 1 - ts) : ts;
-#if R6_PRIO_REMAINING
-        {   // priority = tiles this wave still has to do after this one (capped at 3): a wave that owns one tile more
-            // than its neighbours runs its first tile ahead of them instead of its last one behind them
-            const int64_t left = n_pos - 1 - pos;
-            if (left >= 3) __builtin_amdgcn_s_setprio(3);
-            else if (left == 2) __builtin_amdgcn_s_setprio(2);
-            else if (left == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-#else
         if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
         else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
         else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
-#endif
         ++tile_no;
         TileIn cur;
         bool overflow;
@@ -1007,7 +990,7 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
         // ONE: n_substeps == 1 (the reference's configuration) gets the straight-line integrator instance;
         // NT: non-temporal output stores for working sets far beyond the Infinity Cache
         const bool nt = b.n >= R6_NT_MIN_ENVS;
-        if (p.n_substeps == 1 && !R6_DISABLE_ONE) kernel = nt ? r6::step_kernel<INTEG, SHAPING, OD, true, true> : r6::step_kernel<INTEG, SHAPING, OD, false, true>;
+        if (p.n_substeps == 1) kernel = nt ? r6::step_kernel<INTEG, SHAPING, OD, true, true> : r6::step_kernel<INTEG, SHAPING, OD, false, true>;
         else if (nt) kernel = r6::step_kernel<INTEG, SHAPING, OD, true, false>;
     }
     const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);   // both forms share launch bounds and occupancy
