@@ -301,8 +301,12 @@ def main(argv=None):
         env._bench_out = env.step_k(pool[0])
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if multi:
-            dist.barrier()
+            if on_gpu_pg:
+                dist.barrier(device_ids=[local])     # RCCL: name the device, or the barrier guesses it from the rank
+            else:
+                dist.barrier()
         torch.cuda.synchronize(dev)
 
     stream = torch.cuda.current_stream(dev)
@@ -350,7 +354,7 @@ def main(argv=None):
         print(json.dumps(line), flush=True)
 
     if multi:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
