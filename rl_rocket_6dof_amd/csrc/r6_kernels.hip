@@ -964,6 +964,23 @@ int resident_blocks(K kernel, int slot) {
     return v;
 }
 
+// True when the current device shows all 8 XCDs of an MI355X as one device (SPX mode: 256 CUs), which is what the
+// XCD-parity split assumes (workgroup i on XCD i % 8).  A partitioned device (CPX: 32 CUs = one XCD) gets equal shares.
+bool device_has_eight_xcds() {
+    static std::atomic<int> cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        (void)hipGetLastError();
+        v = (cus == 256) ? 1 : -1;
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v > 0;
+}
+
 // Share of the tiles handed to the workgroups on even XCDs, in 1/65536 (0 = no split).  Defaults from a sweep at
 // N = 2^20 (0.50 / 0.52 / 0.54 / 0.56: RK4 39.5 / 38.8 / 38.3 / 38.6 us, fused stack 43.6 / 42.8 / 41.8 / 41.5, Euler 35.2 /
 // 35.3 / 35.2 / 34.1): the even XCDs of an MI355X finish equal shares ~1.19x sooner (load latency, see step_kernel).
@@ -1008,7 +1025,7 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     }
     // XCD-aware split (see step_kernel): only for the persistent grid, where every wave walks several tiles
     uint32_t even_share = 0;
-    if (blocks == cap && (blocks % 8) == 0 && n_tiles >= 2 * blocks * r6::kWaves) even_share = even_xcd_share_q16(INTEG);
+    if (blocks == cap && (blocks % 8) == 0 && n_tiles >= 2 * blocks * r6::kWaves && device_has_eight_xcds()) even_share = even_xcd_share_q16(INTEG);
     // Order of the tiles on odd steps (see step_kernel).  Measured in one process at N = 2^20 / 2^21 / 2^22 (us per step;
     // as even steps | every wave's list backwards | whole range mirrored): RK4 38.0 | 39.4 | 38.8, 85.2 | 90.8 | 90.1,
     // 154 | 159 | 162 (the last size runs the dispatcher-balanced grid, where only "mirrored" exists: its three numbers are
