@@ -246,6 +246,30 @@ int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std
                      float clip_range, float vf_coef, float ent_coef, float *grad_mean, float *grad_value,
                      float *grad_log_std, float *stats, void *stream);
 
+/* ---- the whole PPO minibatch step's gradient in one launch ---------------------------------------------------------
+ * SB3 1.6 `PPO.train` per minibatch (stable_baselines3/ppo/ppo.py, behind main_6DOF.py:107-139): evaluate_actions on the
+ * minibatch rows, the clipped-surrogate / value / entropy loss of r6_ppo_loss_grad, and loss.backward() through the
+ * actor-critic -- forward, loss and backward fused, on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32).  Supported
+ * net: the reference's topology, ONE shared tanh trunk obs -> 128 -> 64 with a 3-output action head and a value head
+ * (R6PolicyNet.shared = 1, hidden1 = 128, hidden2 = 64, obs_dim 13 | 14).
+ *   obs (rows, obs_dim), action (rows, 3), old_logp / adv / ret [rows]: the rollout buffer; `index` [n] (int64, or NULL for
+ *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
+ *   grad: WRITTEN (not accumulated), torch.nn.Linear layouts like the weights.  stats [8] written: pg_loss, v_loss, entropy,
+ *   clip_frac, approx_kl, n.  scratch: r6_ppo_scratch_floats() floats of device memory owned by the caller. */
+typedef struct R6PolicyGrad {
+    float *w1, *b1;             /* trunk layer 1: [128][obs_dim], [128] */
+    float *w2, *b2;             /* trunk layer 2: [64][128], [64] */
+    float *pi_w3, *pi_b3;       /* action head: [3][64], [3] */
+    float *vf_w3, *vf_b3;       /* value head: [1][64], [1] */
+    float *log_std;             /* [3] */
+} R6PolicyGrad;
+size_t r6_policy_grad_size(void);   /* sizeof(R6PolicyGrad) */
+size_t r6_ppo_scratch_floats(void);
+int r6_ppo_minibatch_grad(const R6PolicyNet *net, const float *obs, const float *action, const float *old_logp,
+                          const float *adv, const float *ret, const int64_t *index, int64_t n, const float *adv_norm,
+                          float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad *grad, float *stats,
+                          float *scratch, size_t scratch_floats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

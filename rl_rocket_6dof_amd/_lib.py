@@ -7,13 +7,14 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .params import R6Buffers, R6Params, R6PolicyNet, R6StepK
+from .params import R6Buffers, R6Params, R6PolicyGrad, R6PolicyNet, R6StepK
 
 ABI_VERSION = 4
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
-           "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad")
+           "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad",
+           "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad")
 
 
 class R6Error(RuntimeError):
@@ -55,6 +56,13 @@ def load(path: str | None = None):
     lib.r6_policy_act.argtypes = [C.POINTER(R6PolicyNet), vp, i64, vp, vp, vp, vp, u64, u64, u64, C.c_int, vp]
     f32 = C.c_float
     lib.r6_ppo_loss_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
+    lib.r6_policy_grad_size.restype = C.c_size_t
+    lib.r6_ppo_scratch_floats.restype = C.c_size_t
+    lib.r6_ppo_minibatch_grad.argtypes = [C.POINTER(R6PolicyNet), vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32,
+                                          C.POINTER(R6PolicyGrad), vp, vp, C.c_size_t, vp]
+    lib.r6_ppo_minibatch_grad.restype = C.c_int
+    if lib.r6_policy_grad_size() != C.sizeof(R6PolicyGrad):
+        raise ImportError("R6PolicyGrad layout mismatch between params.py and libr6dof.so: rebuild")
     for name in ("r6_step", "r6_step_k", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):
         getattr(lib, name).restype = C.c_int
     if lib.r6_abi_version() != ABI_VERSION:

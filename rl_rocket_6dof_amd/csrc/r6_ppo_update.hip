@@ -1,0 +1,485 @@
+// Fused PPO minibatch gradient: forward, loss and the WHOLE backward pass of the
+// actor-critic in one launch -- parameter gradients come out, no activation ever goes to HBM.
+//
+// What it replaces: one minibatch step of SB3 1.6 `PPO.train` (stable_baselines3/ppo/ppo.py; the reference trains
+// through it, main_6DOF.py:107-139) on the topology the reference uses, `policy_kwargs={'net_arch': [128, 64]}` =
+// ONE shared tanh trunk obs -> 128 -> 64 with a 3-output action head and a scalar value head (R6PolicyNet.shared = 1):
+//     policy.evaluate_actions(obs[mb], actions[mb]) ; ratio / clipped surrogate / value MSE / entropy ; loss.backward()
+// In torch (ppo.py of this package) that is 5 row gathers, 4 GEMMs forward, 7 GEMMs backward -- the three tall
+// weight-gradient products (64 x 65536)(65536 x 128) are the expensive ones -- and ~40 elementwise / reduction kernels:
+// 0.52 ms of GPU time for 65 536 samples.  Here a wave owns a tile of 32 samples (the MFMA column block):
+//
+//   forward   z1 = W1 x, a1 = tanh z1, z2 = W2 a1, a2 = tanh z2 on the matrix cores (v_mfma_f32_32x32x2_f32: exact
+//             fp32 products and accumulation, so the gradients carry no reduced-precision term), out^T[feature][sample]
+//             = W[feature][k] * act^T[k][sample] as in r6_policy.hip: a layer's accumulator block IS the next layer's
+//             B operand; heads (4 outputs) on the VALU;
+//   loss      per sample, the formulas of r6_ppo_loss_grad -> g = d loss / d (mean0, mean1, mean2, value);
+//   backward  delta2 = (W3^T g) (1 - a2^2) on the VALU; delta1 = (W2^T delta2) (1 - a1^2) on the matrix cores through
+//             a W2^T image, delta2's accumulator-layout registers being the B operand again;
+//   weight gradients  dW2 = delta2 a1^T, dW1 = delta1 x^T, dW3 = g a2^T, db2 = delta2 1: products that CONTRACT OVER
+//             THE SAMPLES, i.e. over the lane dimension of everything above.  The tiles are transposed through a per-wave
+//             LDS buffer ([feature][sample], pitch 33) and read back as MFMA operands with the sample index on K; the
+//             sums live in accumulator registers (16 blocks of 32 x 32 per wave, 256 registers) for the whole launch.
+// After its last tile a workgroup adds its waves' blocks in LDS and writes one partial set; a second small launch sums
+// the partial sets of all workgroups and scatters them into torch's parameter layouts.
+//
+// Tested against autograd of the torch modules (tests/test_gpu_ppo.py): every gradient within 2e-5 of its tensor's
+// largest entry, loss statistics to 1e-5.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/r6dof.h"
+
+extern "C" void r6_internal_set_error(const char* what);
+
+namespace r6u {
+
+constexpr int kBlock = 256, kWaves = 4;
+constexpr int kPitch = 33;                 // floats per row of the transposed tiles (32 samples + 1: conflict-free columns)
+constexpr int kNumBlocks = 16;             // 32x32 accumulator blocks per wave: dW2 (8), dW1 (4), dW3^T (2), db2 (2)
+constexpr int kScalars = 16;               // db3[4], dlog_std[3], pg, v, clip_frac, kl (+ pad)
+constexpr int kPartial = kNumBlocks * 1024 + kScalars;
+constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// tanh(z) = 1 - 2 / (exp(2z) + 1): v_exp_f32 + v_rcp_f32, absolute error ~1e-7, saturates cleanly
+__device__ __forceinline__ float tanh_fast(float z) {
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(kExpScale * z) + 1.0f), 1.0f);
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS image of the weights (floats), one value per lane and MFMA step (H1, H2 multiples of 32):
+//   w1   [H1/32][8][64]            A of layer 1: lane l, step s: W1[blk*32 + (l&31)][k = 2s + (l>>5)]; k == OD carries b1
+//   w2   [H2/32][H1/32][16][64]    A of layer 2: W2[mb*32 + (l&31)][32b + row(r, l>>5)]
+//   w2t  [H1/32][H2/32][16][64]    A of the delta chain: W2[32c + row(r, l>>5)][ib*32 + (l&31)]
+//   b2   [H2/32][2][16]            accumulator init of layer 2: b2[mb*32 + row(r,h)]
+//   w3   [2][H2/32][16][4]         heads: {pi_w3[0..2][32c + row(r,h)], vf_w3[32c + row(r,h)]}
+template <int H1, int H2>
+struct Image {
+    static constexpr int oW1 = 0, kW1 = (H1 / 32) * 8 * 64;
+    static constexpr int oW2 = oW1 + kW1, kW2 = (H2 / 32) * (H1 / 32) * 16 * 64;
+    static constexpr int oW2T = oW2 + kW2;
+    static constexpr int oB2 = oW2T + kW2, kB2 = (H2 / 32) * 2 * 16;
+    static constexpr int oW3 = oB2 + kB2, kW3 = 2 * (H2 / 32) * 16 * 4;
+    static constexpr int kImage = oW3 + kW3;
+    // per-wave staging (transposed tiles): a2 / delta2 [H2][kPitch], one 32-row block [32][kPitch], x [16][kPitch], g [4][kPitch]
+    static constexpr int sT2 = 0, sBlk = H2 * kPitch, sX = sBlk + 32 * kPitch, sG = sX + 16 * kPitch;
+    static constexpr int kStage = sG + 4 * kPitch;
+    static constexpr int kTotal = kImage + kWaves * kStage;
+};
+
+struct Args {
+    const float* obs;
+    const float* action;
+    const float* old_logp;
+    const float* adv;
+    const float* ret;
+    const int64_t* index;   // minibatch rows (NULL: rows 0..n-1)
+    const float* adv_norm;  // [mean, 1 / (std + 1e-8)] or NULL
+    int64_t n;
+    float clip, vf_coef, ent_coef;
+};
+
+template <int H1, int H2, int OD>
+__global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet net, const Args a, float* __restrict__ partial) {
+    using Im = Image<H1, H2>;
+    constexpr int B1 = H1 / 32, B2 = H2 / 32;
+    static_assert(B2 == 2 && B1 * B2 + B1 + 2 * B2 == kNumBlocks, "accumulator block count is sized for H2 = 64, H1 = 128");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int col = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- stage the weight images -------------------------------------------------------------------------------------
+    for (int e = tid; e < Im::kW1; e += kBlock) {
+        const int l = e & 63, s = (e >> 6) & 7, blk = e >> 9;
+        const int k = 2 * s + (l >> 5), m = blk * 32 + (l & 31);
+        lds[Im::oW1 + e] = (k < OD) ? net.pi_w1[m * OD + k] : ((k == OD) ? net.pi_b1[m] : 0.0f);
+    }
+    for (int e = tid; e < Im::kW2; e += kBlock) {
+        const int l = e & 63, r = (e >> 6) & 15, rest = e >> 10;
+        {   // w2: rest = mb * B1 + b
+            const int b = rest % B1, mb = rest / B1;
+            lds[Im::oW2 + e] = net.pi_w2[(mb * 32 + (l & 31)) * H1 + 32 * b + rowmap(r, l >> 5)];
+        }
+        {   // w2t: rest = ib * B2 + c
+            const int c = rest % B2, ib = rest / B2;
+            lds[Im::oW2T + e] = net.pi_w2[(32 * c + rowmap(r, l >> 5)) * H1 + ib * 32 + (l & 31)];
+        }
+    }
+    for (int e = tid; e < Im::kB2; e += kBlock) {
+        const int r = e & 15, hh = (e >> 4) & 1, mb = e >> 5;
+        lds[Im::oB2 + e] = net.pi_b2[mb * 32 + rowmap(r, hh)];
+    }
+    for (int e = tid; e < Im::kW3; e += kBlock) {
+        const int o = e & 3, r = (e >> 2) & 15, rest = e >> 6;
+        const int c = rest % B2, hh = rest / B2;
+        const int k = 32 * c + rowmap(r, hh);
+        lds[Im::oW3 + e] = (o < 3) ? net.pi_w3[o * H2 + k] : net.vf_w3[k];
+    }
+    __syncthreads();
+
+    float* st = lds + Im::kImage + wave * Im::kStage;   // this wave's staging area
+    const float b3_0 = net.pi_b3[0], b3_1 = net.pi_b3[1], b3_2 = net.pi_b3[2], b3_v = net.vf_b3[0];
+    const float ls0 = net.log_std[0], ls1 = net.log_std[1], ls2 = net.log_std[2];
+    const float iv0 = __expf(-2.0f * ls0), iv1 = __expf(-2.0f * ls1), iv2 = __expf(-2.0f * ls2);
+    const float a_mean = a.adv_norm ? a.adv_norm[0] : 0.0f, a_istd = a.adv_norm ? a.adv_norm[1] : 1.0f;
+    const float inv_n = 1.0f / (float)a.n;
+
+    // ---- accumulators of the launch -----------------------------------------------------------------------------------
+    f32x16 acc_w2[B2][B1], acc_w1[B1], acc_w3[B2], acc_b2[B2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+            acc_w3[mb][r] = 0.0f;
+            acc_b2[mb][r] = 0.0f;
+#pragma unroll
+            for (int ib = 0; ib < B1; ++ib) acc_w2[mb][ib][r] = 0.0f;
+        }
+#pragma unroll
+        for (int ib = 0; ib < B1; ++ib) acc_w1[ib][r] = 0.0f;
+    }
+    float sc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // db3[4], dlog_std[3], pg, v, clip_frac, kl
+
+    const int64_t n_tiles = (a.n + 31) >> 5;
+#pragma unroll 1
+    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += (int64_t)gridDim.x * kWaves) {
+        const int64_t si = t * 32 + col;
+        const bool live = si < a.n;
+        const int64_t row = live ? (a.index ? a.index[si] : si) : 0;
+
+        // ---- x: this lane's 8 features k = 2s + h of its sample (B operand of layer 1), bias column k == OD = 1 --------
+        float xk[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = 2 * s + h;
+            xk[s] = 0.0f;
+            if (live) {
+                if (k < OD) xk[s] = a.obs[row * OD + k];
+                else if (k == OD) xk[s] = 1.0f;
+            }
+        }
+
+        // ---- forward -----------------------------------------------------------------------------------------------------
+        f32x16 a1[B1], a2[B2];
+#pragma unroll
+        for (int blk = 0; blk < B1; ++blk) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) z = mfma(lds[Im::oW1 + (blk * 8 + s) * 64 + lane], xk[s], z);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[blk][r] = tanh_fast(z[r]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = lds[Im::oB2 + (mb * 2 + h) * 16 + r];
+#pragma unroll
+            for (int b = 0; b < B1; ++b) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z = mfma(lds[Im::oW2 + ((mb * B1 + b) * 16 + r) * 64 + lane], a1[b][r], z);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[mb][r] = tanh_fast(z[r]);
+        }
+        float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* w3 = &lds[Im::oW3 + ((h * B2 + mb) * 16 + r) * 4];
+                part[0] = fmaf(w3[0], a2[mb][r], part[0]);
+                part[1] = fmaf(w3[1], a2[mb][r], part[1]);
+                part[2] = fmaf(w3[2], a2[mb][r], part[2]);
+                part[3] = fmaf(w3[3], a2[mb][r], part[3]);
+            }
+        }
+        const float m0 = part[0] + __shfl_xor(part[0], 32) + b3_0;
+        const float m1 = part[1] + __shfl_xor(part[1], 32) + b3_1;
+        const float m2 = part[2] + __shfl_xor(part[2], 32) + b3_2;
+        const float vv = part[3] + __shfl_xor(part[3], 32) + b3_v;
+
+        // ---- loss and its gradient w.r.t. (mean, value): r6_ppo_loss_grad's formulas, per sample --------------------------
+        float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) {
+            const float d0 = a.action[3 * row + 0] - m0, d1 = a.action[3 * row + 1] - m1, d2 = a.action[3 * row + 2] - m2;
+            const float q0 = d0 * d0 * iv0, q1 = d1 * d1 * iv1, q2 = d2 * d2 * iv2;
+            const float logp = -0.5f * (q0 + q1 + q2) - (ls0 + ls1 + ls2) - 2.756815599614018f;
+            const float dl = logp - a.old_logp[row];
+            const float ratio = __expf(dl);
+            const float A = (a.adv[row] - a_mean) * a_istd;
+            const float s1 = A * ratio, s2 = A * fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
+            const bool active = !((A > 0.0f && ratio > 1.0f + a.clip) || (A < 0.0f && ratio < 1.0f - a.clip));
+            const float g_logp = active ? -s1 * inv_n : 0.0f;
+            g[0] = g_logp * d0 * iv0;
+            g[1] = g_logp * d1 * iv1;
+            g[2] = g_logp * d2 * iv2;
+            const float ve = vv - a.ret[row];
+            g[3] = a.vf_coef * 2.0f * ve * inv_n;
+            if (h == 0) {   // each sample is counted once (both lane halves hold it)
+                sc[0] += g[0];
+                sc[1] += g[1];
+                sc[2] += g[2];
+                sc[3] += g[3];
+                sc[4] += g_logp * (q0 - 1.0f);
+                sc[5] += g_logp * (q1 - 1.0f);
+                sc[6] += g_logp * (q2 - 1.0f);
+                sc[7] += -fminf(s1, s2);
+                sc[8] += ve * ve;
+                sc[9] += (fabsf(ratio - 1.0f) > a.clip) ? 1.0f : 0.0f;
+                sc[10] += (ratio - 1.0f) - dl;
+            }
+        }
+
+        // ---- dW3^T[f][o] += sum_s a2[f][s] g[o][s]: a2 and g transposed through LDS, samples on K ---------------------------
+        wave_sync();   // the previous tile's readers of the staging area are done
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[Im::sT2 + (mb * 32 + rowmap(r, h)) * kPitch + col] = a2[mb][r];
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) st[Im::sG + o * kPitch + col] = g[o];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) st[Im::sX + (2 * s + h) * kPitch + col] = xk[s];
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float bg = (col < 4) ? st[Im::sG + col * kPitch + 2 * s + h] : 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) acc_w3[mb] = mfma(st[Im::sT2 + (mb * 32 + col) * kPitch + 2 * s + h], bg, acc_w3[mb]);
+        }
+
+        // ---- delta2 = (W3^T g) (1 - a2^2): this lane half's 16 rows per block ------------------------------------------------
+        f32x16 d2[B2];
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* w3 = &lds[Im::oW3 + ((h * B2 + mb) * 16 + r) * 4];
+                const float up = fmaf(w3[0], g[0], fmaf(w3[1], g[1], fmaf(w3[2], g[2], w3[3] * g[3])));
+                d2[mb][r] = up * fmaf(-a2[mb][r], a2[mb][r], 1.0f);
+            }
+        }
+        wave_sync();   // dW3's reads of the a2 tile are done: delta2 takes its place
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[Im::sT2 + (mb * 32 + rowmap(r, h)) * kPitch + col] = d2[mb][r];
+        }
+        wave_sync();
+        // db2[f] += sum_s delta2[f][s]: B = a column of ones (n == 0)
+        const float ones0 = (col == 0) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) acc_b2[mb] = mfma(st[Im::sT2 + (mb * 32 + col) * kPitch + 2 * s + h], ones0, acc_b2[mb]);
+        }
+
+        // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) ----------------------
+#pragma unroll
+        for (int ib = 0; ib < B1; ++ib) {
+            wave_sync();   // the block buffer's previous readers are done
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[Im::sBlk + rowmap(r, h) * kPitch + col] = a1[ib][r];
+            wave_sync();
+            // dW2[f2][i] += sum_s delta2[f2][s] a1[i][s]
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float ba = st[Im::sBlk + col * kPitch + 2 * s + h];
+#pragma unroll
+                for (int mb = 0; mb < B2; ++mb) acc_w2[mb][ib] = mfma(st[Im::sT2 + (mb * 32 + col) * kPitch + 2 * s + h], ba, acc_w2[mb][ib]);
+            }
+            // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
+            f32x16 d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < B2; ++c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1 = mfma(lds[Im::oW2T + ((ib * B2 + c) * 16 + r) * 64 + lane], d2[c][r], d1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ib][r], a1[ib][r], 1.0f);
+            wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[Im::sBlk + rowmap(r, h) * kPitch + col] = d1[r];
+            wave_sync();
+            // dW1[i][k] += sum_s delta1[i][s] x[k][s]   (k == OD: db1, through x's column of ones)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float bx = (col < 16) ? st[Im::sX + col * kPitch + 2 * s + h] : 0.0f;
+                acc_w1[ib] = mfma(st[Im::sBlk + col * kPitch + 2 * s + h], bx, acc_w1[ib]);
+            }
+        }
+    }
+
+    // ---- workgroup reduction: scalars, then the 16 accumulator blocks one after the other through one LDS block ---------------
+    __syncthreads();
+    float* red = lds + Im::kImage;                 // [1024] block buffer, staging areas are free now
+    float* reds = red + 1024;                      // [kScalars]
+    float* out = partial + (int64_t)blockIdx.x * kPartial;
+    if (tid < kScalars) reds[tid] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        float v = sc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) atomicAdd(&reds[k], v);
+    }
+    __syncthreads();
+    if (tid < kScalars) out[kNumBlocks * 1024 + tid] = reds[tid];
+    auto flush = [&](const f32x16& acc, int blk) __attribute__((always_inline)) {
+        __syncthreads();
+        for (int e = tid; e < 1024; e += kBlock) red[e] = 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(&red[rowmap(r, h) * 32 + col], acc[r]);   // canonical [m][n]
+        __syncthreads();
+        for (int e = tid; e < 1024; e += kBlock) out[blk * 1024 + e] = red[e];
+    };
+#pragma unroll
+    for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+        for (int ib = 0; ib < B1; ++ib) flush(acc_w2[mb][ib], mb * B1 + ib);
+    }
+#pragma unroll
+    for (int ib = 0; ib < B1; ++ib) flush(acc_w1[ib], B2 * B1 + ib);
+#pragma unroll
+    for (int mb = 0; mb < B2; ++mb) flush(acc_w3[mb], B2 * B1 + B1 + mb);
+#pragma unroll
+    for (int mb = 0; mb < B2; ++mb) flush(acc_b2[mb], B2 * B1 + B1 + B2 + mb);
+}
+
+// Sums the partial sets of all workgroups and scatters them into torch's parameter layouts ([out][in] row-major).
+template <int H1, int H2, int OD>
+__global__ __launch_bounds__(256) void ppo_grad_reduce_kernel(const float* __restrict__ partial, const int n_sets, const R6PolicyGrad gr,
+                                                              const float* __restrict__ log_std, const float ent_coef, const float inv_n,
+                                                              const float n_samples, float* __restrict__ stats) {
+    constexpr int B1 = H1 / 32, B2 = H2 / 32;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kPartial) return;
+    float v = 0.0f;
+    for (int s = 0; s < n_sets; ++s) v += partial[(int64_t)s * kPartial + e];
+    if (e < kNumBlocks * 1024) {
+        const int blk = e >> 10, m = (e >> 5) & 31, nn = e & 31;
+        if (blk < B2 * B1) {                       // dW2[mb*32 + m][ib*32 + n]
+            const int mb = blk / B1, ib = blk % B1;
+            gr.w2[(mb * 32 + m) * H1 + ib * 32 + nn] = v;
+        } else if (blk < B2 * B1 + B1) {           // dW1[ib*32 + m][k = n], k == OD: db1
+            const int ib = blk - B2 * B1;
+            if (nn < OD) gr.w1[(ib * 32 + m) * OD + nn] = v;
+            else if (nn == OD) gr.b1[ib * 32 + m] = v;
+        } else if (blk < B2 * B1 + B1 + B2) {      // dW3^T[mb*32 + m][o = n]
+            const int mb = blk - (B2 * B1 + B1);
+            if (nn < 3) gr.pi_w3[nn * H2 + mb * 32 + m] = v;
+            else if (nn == 3) gr.vf_w3[mb * 32 + m] = v;
+        } else {                                   // db2[mb*32 + m] in column 0
+            const int mb = blk - (B2 * B1 + B1 + B2);
+            if (nn == 0) gr.b2[mb * 32 + m] = v;
+        }
+    } else {
+        const int k = e - kNumBlocks * 1024;
+        if (k < 3) gr.pi_b3[k] = v;
+        else if (k == 3) gr.vf_b3[0] = v;
+        else if (k < 7) gr.log_std[k - 4] = v - ent_coef;   // entropy = sum_i (0.5 + 0.5 ln 2pi + log_std_i): d(ent_coef * -ent) = -ent_coef
+        else if (k == 7) stats[0] = v * inv_n;              // pg loss
+        else if (k == 8) stats[1] = v * inv_n;              // value loss
+        else if (k == 9) stats[3] = v * inv_n;              // clip fraction
+        else if (k == 10) {
+            stats[4] = v * inv_n;                           // approx kl
+            stats[2] = 3.0f * 1.4189385332046727f + log_std[0] + log_std[1] + log_std[2];   // entropy
+            stats[5] = n_samples;
+        }
+    }
+}
+
+template <int H1, int H2, int OD>
+int launch(const R6PolicyNet& net, const Args& a, const R6PolicyGrad& gr, float* stats, float* scratch, size_t scratch_floats,
+           hipStream_t s) {
+    auto kernel = ppo_grad_kernel<H1, H2, OD>;
+    constexpr size_t lds_bytes = sizeof(float) * Image<H1, H2>::kTotal;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    static std::atomic<bool> configured[16];
+    const int di = (dev >= 0 && dev < 16) ? dev : 0;
+    if (!configured[di].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+            r6_internal_set_error("r6_ppo_minibatch_grad: cannot reserve LDS for the weight images");
+            return R6_E_BADARG;
+        }
+        configured[di].store(dev == di, std::memory_order_relaxed);
+    }
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetLastError();
+    const int64_t n_tiles = (a.n + 31) / 32;
+    int64_t blocks = (n_tiles + kWaves - 1) / kWaves;
+    if (blocks > cus) blocks = cus;
+    if ((size_t)blocks * kPartial > scratch_floats) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: scratch too small (r6_ppo_scratch_floats)");
+        return R6_E_BADARG;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, net, a, scratch);
+    hipLaunchKernelGGL((ppo_grad_reduce_kernel<H1, H2, OD>), dim3((kPartial + 255) / 256), dim3(256), 0, s, scratch, (int)blocks, gr,
+                       net.log_std, a.ent_coef, 1.0f / (float)a.n, (float)a.n, stats);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        r6_internal_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+}  // namespace r6u
+
+extern "C" size_t r6_ppo_scratch_floats(void) { return (size_t)256 * r6u::kPartial; }
+extern "C" size_t r6_policy_grad_size(void) { return sizeof(R6PolicyGrad); }
+
+extern "C" int r6_ppo_minibatch_grad(const R6PolicyNet* net, const float* obs, const float* action, const float* old_logp,
+                                     const float* adv, const float* ret, const int64_t* index, int64_t n, const float* adv_norm,
+                                     float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad* grad, float* stats,
+                                     float* scratch, size_t scratch_floats, void* stream) {
+    if (!net || !obs || !action || !old_logp || !adv || !ret || !grad || !stats || !scratch) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: all pointers except index and adv_norm are required");
+        return R6_E_BADARG;
+    }
+    if (n <= 0 || n >= ((int64_t)1 << 31)) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: need 0 < n < 2^31");
+        return R6_E_BADARG;
+    }
+    const R6PolicyNet& p = *net;
+    const R6PolicyGrad& g = *grad;
+    if (!p.shared || p.hidden1 != 128 || p.hidden2 != 64 || (p.obs_dim != 13 && p.obs_dim != 14)) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: supported net: one shared trunk (R6PolicyNet.shared = 1), hidden (128, 64), obs_dim 13|14");
+        return R6_E_BADARG;
+    }
+    if (!p.pi_w1 || !p.pi_b1 || !p.pi_w2 || !p.pi_b2 || !p.pi_w3 || !p.pi_b3 || !p.vf_w3 || !p.vf_b3 || !p.log_std ||
+        !g.w1 || !g.b1 || !g.w2 || !g.b2 || !g.pi_w3 || !g.pi_b3 || !g.vf_w3 || !g.vf_b3 || !g.log_std) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: trunk / head pointers of R6PolicyNet and every R6PolicyGrad pointer are required");
+        return R6_E_BADARG;
+    }
+    r6u::Args a{obs, action, old_logp, adv, ret, index, adv_norm, n, clip_range, vf_coef, ent_coef};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.obs_dim == 13) return r6u::launch<128, 64, 13>(p, a, g, stats, scratch, scratch_floats, s);
+    return r6u::launch<128, 64, 14>(p, a, g, stats, scratch, scratch_floats, s);
+}

@@ -248,3 +248,8 @@ def make_params(env_config: dict, *, integrator: str = "rk4", n_substeps: Option
     else:
         p.vatt_enable, p.vatt_threshold, p.vatt_weight = 1, float(vertical_attitude_reward[0]), float(vertical_attitude_reward[1])
     return p, spec
+
+
+class R6PolicyGrad(C.Structure):
+    """include/r6dof.h ``R6PolicyGrad``: device pointers to the gradient buffers of the shared-trunk net."""
+    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std")]

@@ -56,6 +56,8 @@ class PPOConfig:
                                           # none: with millions of samples per update the std collapses and the late
                                           # phase of training turns erratic)
     seed: int = 42
+    fused_update: bool = True        # forward + loss + the whole backward pass of a minibatch as ONE HIP launch
+                                     # (r6_ppo_minibatch_grad) when the net is the reference's shared trunk [128, 64]
     fused_loss: bool = True          # minibatch loss + its gradient w.r.t. the policy outputs as one HIP launch (GPU only)
     graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
     fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
@@ -94,6 +96,69 @@ class _FusedPPOLoss(torch.autograd.Function):
     def backward(ctx, g, _g_stats):
         gm, gv, gls = ctx.saved_tensors
         return g * gm, g * gv, g * gls, None, None, None, None, None, None, None, None
+
+
+class FusedMinibatchGrad:
+    """One SB3 ``PPO.train`` minibatch -- ``evaluate_actions``, the clipped-surrogate / value / entropy loss and
+    ``loss.backward()`` -- as ONE HIP launch (``r6_ppo_minibatch_grad``, csrc/r6_ppo_update.hip): parameter gradients come out
+    on the matrix cores in exact fp32, no activation goes to HBM and the minibatch rows are picked by index (no gathered
+    copies).  Supported: the reference's topology, one shared tanh trunk obs -> 128 -> 64 with both heads on it
+    (``ActorCritic(net_arch=(128, 64), shared_trunk=True)``).  The gradient tensors are persistent and become the
+    parameters' ``.grad``, so clipping, the all-reduce and Adam run unchanged behind it."""
+
+    ARCH = (128, 64)
+
+    @staticmethod
+    def supports(policy) -> bool:
+        lin = [m for m in policy.pi if isinstance(m, nn.Linear)]
+        return bool(getattr(policy, "shared_trunk", False)) and len(lin) == 3 and \
+            (lin[0].out_features, lin[1].out_features) == FusedMinibatchGrad.ARCH and lin[0].in_features in (13, 14) and \
+            lin[2].out_features == 3 and policy.log_std.is_cuda
+
+    def __init__(self, policy, lib_path=None):
+        import ctypes as C
+
+        from . import _lib
+        from .params import R6PolicyGrad, R6PolicyNet
+
+        if not self.supports(policy):
+            raise ValueError("FusedMinibatchGrad needs ActorCritic(net_arch=(128, 64), shared_trunk=True) on a GPU")
+        self.lib = _lib.load(lib_path)
+        pi = [m for m in policy.pi if isinstance(m, nn.Linear)]
+        vf_head = [m for m in policy.vf if isinstance(m, nn.Linear)][-1]
+        self.params = [pi[0].weight, pi[0].bias, pi[1].weight, pi[1].bias, pi[2].weight, pi[2].bias, vf_head.weight, vf_head.bias,
+                       policy.log_std]
+        for t in self.params:
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("policy parameters must be contiguous float32 CUDA tensors")
+        self.device = self.params[0].device
+        self.obs_dim = pi[0].in_features
+        self.grads = [torch.zeros_like(t) for t in self.params]
+        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.scratch = torch.empty(int(self.lib.r6_ppo_scratch_floats()), dtype=torch.float32, device=self.device)
+        self._net, self._grad, self._C = R6PolicyNet(), R6PolicyGrad(), C
+        for name, t in zip(("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.grads):
+            setattr(self._grad, name, t.data_ptr())
+
+    def __call__(self, obs, action, old_logp, adv, ret, index, adv_norm, clip, vf_coef, ent_coef):
+        """Writes the gradients of the minibatch ``index`` (int64 rows of the rollout tensors; None = all rows) into the
+        parameters' ``.grad`` and returns the stats tensor [pg_loss, v_loss, entropy, clip_frac, approx_kl, n, -, -]."""
+        C, net = self._C, self._net
+        net.obs_dim, net.hidden1, net.hidden2, net.shared = self.obs_dim, self.ARCH[0], self.ARCH[1], 1
+        for name, t in zip(("pi_w1", "pi_b1", "pi_w2", "pi_b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.params):
+            setattr(net, name, t.data_ptr())
+        n = int(index.numel()) if index is not None else int(obs.shape[0])
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_ppo_minibatch_grad(C.byref(net), ptr(obs), ptr(action), ptr(old_logp), ptr(adv), ptr(ret), ptr(index), n,
+                                                ptr(adv_norm), float(clip), float(vf_coef), float(ent_coef), C.byref(self._grad),
+                                                ptr(self.stats), ptr(self.scratch), self.scratch.numel(),
+                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        from . import _lib
+        _lib.check(rc, "r6_ppo_minibatch_grad", self.lib)
+        for p_, g_ in zip(self.params, self.grads):
+            p_.grad = g_
+        return self.stats
 
 
 class _TallLinearFn(torch.autograd.Function):
@@ -264,6 +329,9 @@ class PPO:
         self.ret = torch.zeros((T, n), **f32)
         self._obs = None
         self.num_timesteps = 0
+        self.fused_update = None
+        if cfg.fused_update and self.device.type == "cuda" and FusedMinibatchGrad.supports(self.policy) and env.obs_dim in (13, 14):
+            self.fused_update = FusedMinibatchGrad(self.policy)
         self.fused = None
         self._rollout_step = 0
         if cfg.fused_policy and self.device.type == "cuda":
@@ -353,6 +421,21 @@ class PPO:
         """One SB3 ``PPO.train`` minibatch: loss, backward, (all-reduce), grad-norm clip, Adam; stats into ``acc``."""
         cfg = self.cfg
         obs, act, old_logp, adv, ret = flat
+        if self.fused_update is not None:
+            # forward + loss + backward of the whole minibatch in one launch; rows picked by index inside the kernel
+            norm = None
+            if cfg.normalize_advantage and mb.numel() > 1:
+                std, mean = torch.std_mean(adv[mb])
+                norm = torch.stack([mean, 1.0 / (std + 1e-8)])
+            st = self.fused_update(obs, act, old_logp, adv, ret, mb, norm, cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
+            self._sync_grads()
+            torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
+            self.opt.step()
+            with torch.no_grad():
+                if cfg.log_std_min is not None:
+                    self.policy.log_std.clamp_(min=cfg.log_std_min)
+                acc += st[:5]
+            return
         a = adv[mb]
         fused = cfg.fused_loss and self.device.type == "cuda"
         if fused:

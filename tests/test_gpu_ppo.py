@@ -131,3 +131,64 @@ def test_fused_ppo_loss_matches_autograd():
         for got, want in zip(st[:5].tolist(), (pg, v, ent, cf, kl)):
             assert abs(got - float(want)) <= 3e-5 * max(1.0, abs(float(want)))
         assert int(st[5]) == n
+
+
+@pytest.mark.parametrize("obs_dim,n_rows,n_mb,norm_adv", [(13, 5000, 3001, True), (14, 70000, 65536, False), (13, 300, 17, True)])
+def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv):
+    """r6_ppo_minibatch_grad -- forward, PPO loss and the whole backward pass of the reference's shared-trunk net
+    [128, 64] in one launch -- against torch autograd through the same modules on the same minibatch (rows picked by
+    index): every parameter gradient within 2e-5 of its tensor's largest entry, the loss statistics within 3e-5."""
+    import math
+
+    import torch
+
+    from rl_rocket_6dof_amd.ppo import ActorCritic, FusedMinibatchGrad
+
+    torch.manual_seed(1)
+    dev = "cuda"
+    pol = ActorCritic(obs_dim, 3, (128, 64), log_std_init=-0.3, shared_trunk=True).to(dev)
+    with torch.no_grad():                       # SB3's init makes the action head tiny (gain 0.01): scale it up so that its
+        pol.pi[-1].weight.mul_(30.0)            # gradient path is not numerically negligible in the comparison
+        pol.pi[-1].bias.uniform_(-0.2, 0.2)
+        pol.log_std.copy_(torch.tensor([-0.4, 0.2, -1.0]))
+    assert FusedMinibatchGrad.supports(pol)
+    obs = torch.randn(n_rows, obs_dim, device=dev) * 0.7
+    with torch.no_grad():
+        mean_all, _ = pol._forward(obs)
+    action = (mean_all + torch.randn(n_rows, 3, device=dev) * pol.log_std.exp()).detach()   # detached: the buffer's actions are data
+    old_logp = pol._logp(mean_all, action).detach() + torch.randn(n_rows, device=dev) * 0.15
+    adv, ret = torch.randn(n_rows, device=dev) * 2 + 0.3, torch.randn(n_rows, device=dev)
+    mb = torch.randperm(n_rows, device=dev)[:n_mb]
+    clip, vf, ec = 0.2, 0.5, 0.01
+
+    # reference: autograd through the torch modules (ppo.PPO's unfused branch)
+    a = adv[mb]
+    if norm_adv:
+        a = (a - a.mean()) / (a.std() + 1e-8)
+    values, logp, entropy = pol.evaluate(obs[mb], action[mb])
+    ratio = torch.exp(logp - old_logp[mb])
+    pg = -torch.min(a * ratio, a * ratio.clamp(1 - clip, 1 + clip)).mean()
+    v_loss = torch.nn.functional.mse_loss(ret[mb], values)
+    ent = -entropy.mean()
+    loss = pg + ec * ent + vf * v_loss
+    params = list(pol.parameters())
+    g_ref = torch.autograd.grad(loss, params)
+    want_stats = (pg, v_loss, -ent, ((ratio - 1).abs() > clip).float().mean(), ((ratio - 1) - (logp - old_logp[mb])).mean())
+
+    fused = FusedMinibatchGrad(pol)
+    norm = torch.stack([adv[mb].mean(), 1.0 / (adv[mb].std() + 1e-8)]) if norm_adv else None
+    for p in params:
+        p.grad = None
+    st = fused(obs, action, old_logp, adv, ret, mb, norm, clip, vf, ec)
+    torch.cuda.synchronize()
+    names = [n for n, _ in pol.named_parameters()]
+    for name, p, gr in zip(names, params, g_ref):
+        assert p.grad is not None, name
+        scale = float(gr.abs().max())
+        err = float((p.grad - gr).abs().max())
+        assert err <= 2e-5 * max(scale, 1e-7) + 1e-10, f"{name}: max abs err {err:.3e} vs scale {scale:.3e}"
+    for got, want in zip(st[:5].tolist(), want_stats):
+        assert abs(got - float(want)) <= 3e-5 * max(1.0, abs(float(want))), (st.tolist(), [float(w) for w in want_stats])
+    assert int(st[5]) == n_mb
+    print(f"[fused minibatch grad od={obs_dim} n={n_mb}] worst relative gradient error "
+          f"{max(float((p.grad - g).abs().max()) / max(float(g.abs().max()), 1e-12) for p, g in zip(params, g_ref)):.2e}")
