@@ -264,6 +264,10 @@ typedef struct R6PolicyGrad {
     float *log_std;             /* [3] */
 } R6PolicyGrad;
 size_t r6_policy_grad_size(void);   /* sizeof(R6PolicyGrad) */
+/* out2 = [mean, 1 / (std + 1e-8)] (unbiased std) of adv[index[0..n)] (index NULL: adv[0..n)): SB3's per-minibatch
+ * advantage normalisation, the `adv_norm` input of the two loss entry points, without a gathered copy.  scratch: 256 doubles
+ * of device memory owned by the caller. */
+int r6_minibatch_adv_norm(const float *adv, const int64_t *index, int64_t n, float *out2, double *scratch, void *stream);
 size_t r6_ppo_scratch_floats(void);
 int r6_ppo_minibatch_grad(const R6PolicyNet *net, const float *obs, const float *action, const float *old_logp,
                           const float *adv, const float *ret, const int64_t *index, int64_t n, const float *adv_norm,

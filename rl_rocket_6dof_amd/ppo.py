@@ -135,10 +135,24 @@ class FusedMinibatchGrad:
         self.obs_dim = pi[0].in_features
         self.grads = [torch.zeros_like(t) for t in self.params]
         self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.norm = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._norm_scratch = torch.zeros(256, dtype=torch.float64, device=self.device)
         self.scratch = torch.empty(int(self.lib.r6_ppo_scratch_floats()), dtype=torch.float32, device=self.device)
         self._net, self._grad, self._C = R6PolicyNet(), R6PolicyGrad(), C
         for name, t in zip(("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.grads):
             setattr(self._grad, name, t.data_ptr())
+
+    def adv_norm(self, adv, index):
+        """[mean, 1 / (std + 1e-8)] of ``adv[index]`` (SB3's per-minibatch advantage normalisation) in one small launch."""
+        C = self._C
+        n = int(index.numel()) if index is not None else int(adv.numel())
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_minibatch_adv_norm(C.c_void_p(adv.data_ptr()), None if index is None else C.c_void_p(index.data_ptr()), n,
+                                                C.c_void_p(self.norm.data_ptr()), C.c_void_p(self._norm_scratch.data_ptr()),
+                                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        from . import _lib
+        _lib.check(rc, "r6_minibatch_adv_norm", self.lib)
+        return self.norm
 
     def __call__(self, obs, action, old_logp, adv, ret, index, adv_norm, clip, vf_coef, ent_coef):
         """Writes the gradients of the minibatch ``index`` (int64 rows of the rollout tensors; None = all rows) into the
@@ -423,10 +437,7 @@ class PPO:
         obs, act, old_logp, adv, ret = flat
         if self.fused_update is not None:
             # forward + loss + backward of the whole minibatch in one launch; rows picked by index inside the kernel
-            norm = None
-            if cfg.normalize_advantage and mb.numel() > 1:
-                std, mean = torch.std_mean(adv[mb])
-                norm = torch.stack([mean, 1.0 / (std + 1e-8)])
+            norm = self.fused_update.adv_norm(adv, mb) if cfg.normalize_advantage and mb.numel() > 1 else None
             st = self.fused_update(obs, act, old_logp, adv, ret, mb, norm, cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
             self._sync_grads()
             torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)

@@ -176,7 +176,10 @@ def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv):
     want_stats = (pg, v_loss, -ent, ((ratio - 1).abs() > clip).float().mean(), ((ratio - 1) - (logp - old_logp[mb])).mean())
 
     fused = FusedMinibatchGrad(pol)
-    norm = torch.stack([adv[mb].mean(), 1.0 / (adv[mb].std() + 1e-8)]) if norm_adv else None
+    norm = fused.adv_norm(adv, mb).clone() if norm_adv else None
+    if norm_adv:
+        want_norm = torch.stack([adv[mb].mean(), 1.0 / (adv[mb].std() + 1e-8)])
+        assert float(((norm - want_norm).abs() / want_norm.abs().clamp_min(1e-6)).max()) < 2e-6, (norm, want_norm)
     for p in params:
         p.grad = None
     st = fused(obs, action, old_logp, adv, ret, mb, norm, clip, vf, ec)
