@@ -274,6 +274,15 @@ int r6_ppo_minibatch_grad(const R6PolicyNet *net, const float *obs, const float 
                           float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad *grad, float *stats,
                           float *scratch, size_t scratch_floats, void *stream);
 
+/* torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.Adam.step() (SB3 1.6's optimiser step, with its
+ * eps 1e-5) for a policy whose parameters / gradients / Adam moments are FLAT device arrays of n floats, in one launch.
+ * lr_dev (device scalar, optional) overrides lr; *step_dev (device int64, starts at 0) is the Adam step count and is
+ * incremented; elements [clamp_off, clamp_off + clamp_n) are floored at clamp_min afterwards (log-std floor; clamp_n = 0: none).
+ * max_grad_norm <= 0: no clipping. */
+int r6_adam_clip_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float max_grad_norm,
+                      float lr, const float *lr_dev, float beta1, float beta2, float eps, int64_t *step_dev,
+                      int64_t clamp_off, int64_t clamp_n, float clamp_min, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -592,7 +592,67 @@ __global__ __launch_bounds__(64) void adv_norm_final_kernel(const double* __rest
     }
 }
 
+// torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() (SB3 1.6's optimiser step:
+// max_grad_norm 0.5, Adam eps 1e-5) for a policy whose parameters, gradients and Adam moments are flat arrays: one
+// workgroup, one launch instead of ~25 (per-tensor norms, the norm of norms, the scale, three multi-tensor Adam kernels,
+// the log-std clamp), which is what a PPO minibatch step spends half its GPU time on once the gradient is one launch.
+__global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                                                         float* __restrict__ v, const int64_t n, const float max_norm, const float lr_value,
+                                                         const float* __restrict__ lr_dev, const float beta1, const float beta2, const float eps,
+                                                         int64_t* __restrict__ step_dev, const int64_t clamp_off, const int64_t clamp_n,
+                                                         const float clamp_min) {
+    __shared__ double red[16];
+    __shared__ float coef_s;
+    double ss = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) ss += (double)grad[i] * (double)grad[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        const float total_norm = (float)sqrt(t);
+        coef_s = (max_norm > 0.0f) ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;   // clip_grad_norm_: clamped to 1
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    const int64_t t = *step_dev + 1;                       // torch.optim.Adam: step count starts at 1
+    const float lr = lr_dev ? *lr_dev : lr_value;
+    const float bc1 = 1.0f - powf(beta1, (float)t), bc2 = 1.0f - powf(beta2, (float)t);
+    const float step_size = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float g = grad[i] * coef;
+        const float mi = fmaf(beta1, m[i], (1.0f - beta1) * g);        // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = fmaf(beta2, v[i], (1.0f - beta2) * g * g);    // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        m[i] = mi;
+        v[i] = vi;
+        float p = param[i] - step_size * mi / fmaf(sqrtf(vi), isq_bc2, eps);
+        if (i >= clamp_off && i < clamp_off + clamp_n) p = fmaxf(p, clamp_min);
+        param[i] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *step_dev = t;
+}
+
 }  // namespace r6u
+
+extern "C" int r6_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
+                                 float lr, const float* lr_dev, float beta1, float beta2, float eps, int64_t* step_dev,
+                                 int64_t clamp_off, int64_t clamp_n, float clamp_min, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n <= 0) {
+        r6_internal_set_error("r6_adam_clip_step: param, grad, exp_avg, exp_avg_sq, step_dev and n > 0 are required");
+        return R6_E_BADARG;
+    }
+    hipLaunchKernelGGL(r6u::adam_clip_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       max_grad_norm, lr, lr_dev, beta1, beta2, eps, step_dev, clamp_off, clamp_n, clamp_min);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        r6_internal_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
 
 extern "C" int r6_minibatch_adv_norm(const float* adv, const int64_t* index, int64_t n, float* out2, double* scratch, void* stream) {
     if (!adv || !out2 || !scratch || n <= 0) {

@@ -133,7 +133,22 @@ class FusedMinibatchGrad:
                 raise ValueError("policy parameters must be contiguous float32 CUDA tensors")
         self.device = self.params[0].device
         self.obs_dim = pi[0].in_features
-        self.grads = [torch.zeros_like(t) for t in self.params]
+        if {id(t) for t in self.params} != {id(t) for t in policy.parameters()}:
+            raise ValueError("the policy has parameters outside the shared trunk and its two heads")
+        # Parameters, gradients and Adam moments as FLAT arrays: every parameter becomes a view into one buffer (same
+        # nn.Parameter objects, same state_dict), so the optimiser step is one launch over n floats (r6_adam_clip_step) and a
+        # multi-rank gradient all-reduce is one bucket with no packing.
+        sizes = [t.numel() for t in self.params]
+        self.flat_p = torch.cat([t.detach().reshape(-1) for t in self.params]).contiguous()
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
+        self.adam_step_count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.grads, off = [], 0
+        for t, k in zip(self.params, sizes):
+            t.data = self.flat_p[off:off + k].view_as(t)
+            self.grads.append(self.flat_g[off:off + k].view_as(t))
+            off += k
+        self.log_std_offset = off - sizes[-1]
         self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.norm = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._norm_scratch = torch.zeros(256, dtype=torch.float64, device=self.device)
@@ -141,6 +156,21 @@ class FusedMinibatchGrad:
         self._net, self._grad, self._C = R6PolicyNet(), R6PolicyGrad(), C
         for name, t in zip(("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.grads):
             setattr(self._grad, name, t.data_ptr())
+
+    def adam_step(self, lr, max_grad_norm: float, log_std_min=None, betas=(0.9, 0.999), eps: float = 1e-5):
+        """``clip_grad_norm_(parameters, max_grad_norm)`` + ``Adam.step()`` (+ the optional log-std floor) on the flat arrays
+        in one launch.  ``lr``: float, or a device scalar tensor (read by the kernel at run time: graph-safe schedules)."""
+        C = self._C
+        lr_dev = C.c_void_p(lr.data_ptr()) if torch.is_tensor(lr) else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_adam_clip_step(
+                C.c_void_p(self.flat_p.data_ptr()), C.c_void_p(self.flat_g.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
+                C.c_void_p(self.exp_avg_sq.data_ptr()), self.flat_p.numel(), float(max_grad_norm if max_grad_norm is not None else 0.0),
+                0.0 if torch.is_tensor(lr) else float(lr), lr_dev, float(betas[0]), float(betas[1]), float(eps),
+                C.c_void_p(self.adam_step_count.data_ptr()), self.log_std_offset, 3 if log_std_min is not None else 0,
+                float(log_std_min if log_std_min is not None else 0.0), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        from . import _lib
+        _lib.check(rc, "r6_adam_clip_step", self.lib)
 
     def adv_norm(self, adv, index):
         """[mean, 1 / (std + 1e-8)] of ``adv[index]`` (SB3's per-minibatch advantage normalisation) in one small launch."""
@@ -439,12 +469,19 @@ class PPO:
             # forward + loss + backward of the whole minibatch in one launch; rows picked by index inside the kernel
             norm = self.fused_update.adv_norm(adv, mb) if cfg.normalize_advantage and mb.numel() > 1 else None
             st = self.fused_update(obs, act, old_logp, adv, ret, mb, norm, cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
-            self._sync_grads()
-            torch.nn.utils.clip_grad_norm_(self.policy.parameters(), cfg.max_grad_norm)
-            self.opt.step()
+            if self.world > 1:     # one bucket, already flat: each rank's mean gradient enters with its share of the samples
+                g = self.fused_update.flat_g
+                g.mul_(self._grad_weight)
+                if dist.get_backend() == "nccl":
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                else:
+                    h = g.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    g.copy_(h)
+            # clip_grad_norm_ + Adam (SB3: eps 1e-5) + the log-std floor: one launch on the flat arrays
+            self.fused_update.adam_step(self.opt.param_groups[0]["lr"], cfg.max_grad_norm, cfg.log_std_min,
+                                        betas=self.opt.param_groups[0]["betas"], eps=self.opt.param_groups[0]["eps"])
             with torch.no_grad():
-                if cfg.log_std_min is not None:
-                    self.policy.log_std.clamp_(min=cfg.log_std_min)
                 acc += st[:5]
             return
         a = adv[mb]

@@ -195,3 +195,45 @@ def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv):
     assert int(st[5]) == n_mb
     print(f"[fused minibatch grad od={obs_dim} n={n_mb}] worst relative gradient error "
           f"{max(float((p.grad - g).abs().max()) / max(float(g.abs().max()), 1e-12) for p, g in zip(params, g_ref)):.2e}")
+
+
+def test_fused_adam_clip_step_matches_torch():
+    """r6_adam_clip_step on the flat parameter / gradient / moment arrays against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.Adam(eps=1e-5) on the same tensors, several steps, with the clip active and inactive and a log-std floor."""
+    import copy
+
+    import torch
+
+    from rl_rocket_6dof_amd.ppo import ActorCritic, FusedMinibatchGrad
+
+    torch.manual_seed(3)
+    dev = "cuda"
+    pol = ActorCritic(13, 3, (128, 64), log_std_init=-2.45, shared_trunk=True).to(dev)
+    ref = copy.deepcopy(pol)
+    fused = FusedMinibatchGrad(pol)                 # flattens pol's parameters in place
+    for (na, a), (nb, b) in zip(pol.named_parameters(), ref.named_parameters()):
+        assert na == nb and torch.equal(a, b)
+    assert sum(p.numel() for p in pol.parameters()) == fused.flat_p.numel() and pol.log_std.data_ptr() == fused.flat_p[fused.log_std_offset:].data_ptr()
+    opt = torch.optim.Adam(ref.parameters(), lr=3e-4, eps=1e-5)
+    lr_dev = torch.tensor(3e-4, device=dev)
+    for it, gscale in enumerate((5.0, 0.01, 1.0, 20.0)):      # total norms above and below max_grad_norm = 0.5
+        g_flat = torch.randn_like(fused.flat_p) * gscale / fused.flat_p.numel() ** 0.5
+        g_flat[fused.log_std_offset:] = torch.tensor([0.5, -0.2, 0.9], device=dev) * gscale     # pushes log_std down: the floor acts
+        fused.flat_g.copy_(g_flat)
+        off = 0
+        for p in fused.params:                           # same gradients for the torch reference, mapped by parameter identity
+            k = p.numel()
+            rp = dict(ref.named_parameters())[[n for n, q in pol.named_parameters() if q is p][0]]
+            rp.grad = g_flat[off:off + k].view_as(rp).clone()
+            off += k
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        opt.step()
+        with torch.no_grad():
+            ref.log_std.clamp_(min=-2.5)
+        fused.adam_step(lr_dev if it % 2 else 3e-4, 0.5, -2.5, betas=(0.9, 0.999), eps=1e-5)
+        torch.cuda.synchronize()
+        for (na, a), (nb, b) in zip(pol.named_parameters(), ref.named_parameters()):
+            err = float((a - b).abs().max())
+            assert err <= 2e-7 + 2e-6 * float(b.abs().max()) * 0 + 3e-7, (it, na, err)
+    assert int(fused.adam_step_count) == 4
+    assert float(pol.log_std.min()) >= -2.5
