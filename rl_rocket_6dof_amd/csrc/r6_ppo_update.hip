@@ -109,6 +109,12 @@ struct Args {
     float clip, vf_coef, ent_coef;
 };
 
+#ifdef R6U_STAMPS
+#define R6U_MARK(k) do { if (tid == 0 && blockIdx.x == 0) { const uint64_t now_ = wall_clock64(); partial[(int64_t)gridDim.x * kPartial + (k)] += (float)(now_ - mark_); mark_ = now_; } } while (0)
+#else
+#define R6U_MARK(k) do { } while (0)
+#endif
+
 template <int H1, int H2, int OD>
 __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet net, const Args a, float* __restrict__ partial) {
     using Im = Image<H1, H2>;
@@ -199,6 +205,9 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
         }
 
+#ifdef R6U_STAMPS
+        uint64_t mark_ = wall_clock64();
+#endif
         // ---- forward -----------------------------------------------------------------------------------------------------
         f32x16 a1[B1], a2[B2];
 #pragma unroll
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             __builtin_amdgcn_sched_barrier(0);   // one chain at a time: operand loads hoisted from later chains would spill, and with
                                                  // one wave per SIMD a scratch access is an exposed memory round trip
         }
+        R6U_MARK(0);   // F1
 #pragma unroll
         for (int mb = 0; mb < B2; ++mb) {
             f32x16 z;
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[mb][r] = tanh_fast(z[r]);
         }
+        R6U_MARK(1);   // F2
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int mb = 0; mb < B2; ++mb) {
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
         }
 
+        R6U_MARK(2);   // heads + loss
         // ---- dW3^T[f][o] += sum_s a2[f][s] g[o][s]: a2 and g transposed through LDS, samples on K ---------------------------
         wave_sync();   // the previous tile's readers of the staging area are done
 #pragma unroll
@@ -309,6 +321,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
         }
 
+        R6U_MARK(3);   // G3 (+ staging of a2, g, x)
         // ---- delta2 = (W3^T g) (1 - a2^2): this lane half's 16 rows per block ------------------------------------------------
         f32x16 d2[B2];
 #pragma unroll
@@ -338,6 +351,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        R6U_MARK(4);   // delta2 + db2
         // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) ----------------------
 #pragma unroll
         for (int ib = 0; ib < B1; ++ib) {
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            R6U_MARK(5);   // G2
             // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
             f32x16 d1;
 #pragma unroll
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ib][r], a1[ib][r], 1.0f);
+            R6U_MARK(6);   // B2
             wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[Im::sBlk + rowmap(r, h) * kPitch + pcol] = d1[r];
@@ -385,6 +401,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 for (int s = 0; s < 16; ++s) acc_w1[ib] = mfma(ta[s], (col < 16) ? bx[s] : 0.0f, acc_w1[ib]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            R6U_MARK(7);   // G1
         }
     }
 

@@ -59,3 +59,9 @@ g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     t_fused()
 print(f"                      fused gradient replayed as a graph {timeit(g.replay):8.1f} us")
+lr = torch.tensor(0.0, device=dev)
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2):
+    t_fused()
+    fused.adam_step(lr, 0.5, -2.5)
+print(f"                      fused gradient + r6_adam_clip_step, as a graph {timeit(g2.replay):8.1f} us   (the whole minibatch step of ppo.PPO)")
