@@ -18,8 +18,9 @@
 //             a W2^T image, delta2's accumulator-layout registers being the B operand again;
 //   weight gradients  dW2 = delta2 a1^T, dW1 = delta1 x^T, dW3 = g a2^T, db2 = delta2 1: products that CONTRACT OVER
 //             THE SAMPLES, i.e. over the lane dimension of everything above.  The tiles are transposed through a per-wave
-//             LDS buffer ([feature][sample], pitch 33) and read back as MFMA operands with the sample index on K; the
-//             sums live in accumulator registers (16 blocks of 32 x 32 per wave, 256 registers) for the whole launch.
+//             LDS buffer ([feature][sample], pitch 36) and read back as MFMA operands with the sample index on K; the
+//             sums live in accumulator registers (12 blocks of 32 x 32 per wave, 192 registers) for the whole launch.
+//             dW3 and db2 (4 + 1 useful columns) are summed on the VALU instead, lane = layer-2 feature = a row of the tile.
 // After its last tile a workgroup adds its waves' blocks in LDS and writes one partial set; a second small launch sums
 // the partial sets of all workgroups and scatters them into torch's parameter layouts.
 //
@@ -43,9 +44,11 @@ constexpr int kBlock = 256, kWaves = 4;
 constexpr int kPitch = 36;                 // floats per row of the transposed tiles: 32 samples (even ones first, then the odd ones) + 4,
                                            // 16-byte aligned rows whose 16-float halves are read conflict-free as 4 x ds_read_b128
 constexpr int kP1 = 12, kP2 = 20;          // floats per lane of the weight images (8 / 16 used): conflict-free ds_read_b128 pitches
-constexpr int kNumBlocks = 16;             // 32x32 accumulator blocks per wave: dW2 (8), dW1 (4), dW3^T (2), db2 (2)
+constexpr int kNumBlocks = 12;             // 32x32 accumulator blocks per wave: dW2 (8), dW1 (4)
+constexpr int kFeat = 5 * 64;              // per layer-2 feature f: dW3^T[f][0..3] and db2[f], summed on the VALU with lane = feature
 constexpr int kScalars = 16;               // db3[4], dlog_std[3], pg, v, clip_frac, kl (+ pad)
-constexpr int kPartial = kNumBlocks * 1024 + kScalars;
+constexpr int kOffFeat = kNumBlocks * 1024, kOffScal = kOffFeat + kFeat;
+constexpr int kPartial = kOffScal + kScalars;   // one workgroup's partial set: [blocks][feat][scalars]
 constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -109,6 +112,20 @@ struct Args {
     float clip, vf_coef, ent_coef;
 };
 
+// End of an MFMA chain: within the chain's region the LDS reads (the NEXT chain's operands) go first, then the 16 MFMAs --
+// left alone the scheduler sinks each ds_read_b128 to just before its first use, and the wave then stalls on an LDS round
+// trip every four MFMAs; across regions nothing moves (operand loads hoisted from later chains would spill).
+#ifndef R6U_NO_CHAIN_FENCE
+#define R6U_CHAIN_FENCE()                                 \
+    do {                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0); \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#else
+#define R6U_CHAIN_FENCE() do { } while (0)
+#endif
+#define R6U_OPAQUE(p) asm volatile("" : "+v"(p))
 #ifdef R6U_STAMPS
 #define R6U_MARK(k) do { if (tid == 0 && blockIdx.x == 0) { const uint64_t now_ = wall_clock64(); partial[(int64_t)gridDim.x * kPartial + (k)] += (float)(now_ - mark_); mark_ = now_; } } while (0)
 #else
@@ -119,7 +136,7 @@ template <int H1, int H2, int OD>
 __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet net, const Args a, float* __restrict__ partial) {
     using Im = Image<H1, H2>;
     constexpr int B1 = H1 / 32, B2 = H2 / 32;
-    static_assert(B2 == 2 && B1 * B2 + B1 + 2 * B2 == kNumBlocks, "accumulator block count is sized for H2 = 64, H1 = 128");
+    static_assert(B2 == 2 && B1 * B2 + B1 == kNumBlocks && 5 * H2 == kFeat, "accumulator block count is sized for H2 = 64, H1 = 128");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -130,11 +147,13 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     const uint64_t ts0 = wall_clock64();
 #endif
     // ---- stage the weight images -------------------------------------------------------------------------------------
+#pragma unroll 8
     for (int e = tid; e < (H1 / 32) * 64 * 8; e += kBlock) {
         const int s = e & 7, l = (e >> 3) & 63, blk = e >> 9;
         const int k = 2 * s + (l >> 5), m = blk * 32 + (l & 31);
         lds[Im::oW1 + (blk * 64 + l) * kP1 + s] = (k < OD) ? net.pi_w1[m * OD + k] : ((k == OD) ? net.pi_b1[m] : 0.0f);
     }
+#pragma unroll 8   // independent gathers from L2: eight in flight per thread instead of one round trip per element
     for (int e = tid; e < B2 * B1 * 64 * 16; e += kBlock) {
         const int r = e & 15, l = (e >> 4) & 63, rest = e >> 10;
         {   // w2: rest = mb * B1 + b
@@ -164,27 +183,53 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     float* st = lds + Im::kImage + wave * Im::kStage;   // this wave's staging area
     const int pcol = (col & 1) * 16 + (col >> 1);        // a sample's place in a transposed row: even samples first, then the odd ones
     const int hoff = h * 16;                             // the 16 places an MFMA chain of this lane half reads (sample 2s + h <-> h*16 + s)
-    const float b3_0 = net.pi_b3[0], b3_1 = net.pi_b3[1], b3_2 = net.pi_b3[2], b3_v = net.vf_b3[0];
-    const float ls0 = net.log_std[0], ls1 = net.log_std[1], ls2 = net.log_std[2];
-    const float iv0 = __expf(-2.0f * ls0), iv1 = __expf(-2.0f * ls1), iv2 = __expf(-2.0f * ls2);
-    const float a_mean = a.adv_norm ? a.adv_norm[0] : 0.0f, a_istd = a.adv_norm ? a.adv_norm[1] : 1.0f;
-    const float inv_n = 1.0f / (float)a.n;
+    // One base register per access pattern, re-made opaque in every tile (R6U_OPAQUE): every LDS address below is then
+    // base + an immediate.  Left to itself the compiler forms the 32 + 32 + ... addresses once, outside the tile loop, and
+    // parks them in scratch -- a scratch reload in front of every ds_read, each an exposed round trip at one wave per SIMD
+    // (measured: 8.5 us of a 36 us tile in the heads alone).
+    // (The opaque values are element offsets into `lds`, not pointers: a pointer that went through an asm statement has
+    // lost its address space and every access through it becomes a flat_load / flat_store.)
+    const int stage0 = Im::kImage + wave * Im::kStage;
+    // Offsets of 16-byte reads are kept in units of four floats (q_*), so that the compiler still sees the alignment behind
+    // the asm statement and emits ds_read_b128 (it falls back to pairs of ds_read2_b32 otherwise).
+    static_assert(Im::oW3 % 4 == 0 && Im::kImage % 4 == 0 && Im::kStage % 4 == 0 && kPitch % 4 == 0 && Im::sG % 4 == 0, "16-byte aligned rows");
+    int q_w3 = (Im::oW3 + h * (B2 * 64)) >> 2;
+    static_assert(Im::oB2 % 4 == 0, "16-byte aligned rows");
+    int q_b2 = (Im::oB2 + h * 16) >> 2;
+    int o_tw = stage0 + 4 * h * kPitch + pcol;           // writes of transposed tiles: element (row(r, h), sample)
+    int q_tr = (stage0 + col * kPitch + hoff) >> 2;      // reads of row `col`, this lane half's 16 samples
+    // wave-uniform scalars live in SGPRs (readfirstlane: the compiler keeps a computed float in a VGPR otherwise)
+    auto uni = [](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float b3_0 = uni(net.pi_b3[0]), b3_1 = uni(net.pi_b3[1]), b3_2 = uni(net.pi_b3[2]), b3_v = uni(net.vf_b3[0]);
+    const float ls0 = uni(net.log_std[0]), ls1 = uni(net.log_std[1]), ls2 = uni(net.log_std[2]);
+    const float iv0 = uni(__expf(-2.0f * ls0)), iv1 = uni(__expf(-2.0f * ls1)), iv2 = uni(__expf(-2.0f * ls2));
+    const float ls_sum = uni(ls0 + ls1 + ls2 + 2.756815599614018f);
+    const float a_mean = uni(a.adv_norm ? a.adv_norm[0] : 0.0f), a_istd = uni(a.adv_norm ? a.adv_norm[1] : 1.0f);
+    const float inv_n = uni(1.0f / (float)a.n);
+    const float vf2n = uni(a.vf_coef * 2.0f * inv_n);
+    // The 11 running sums of a lane (db3[4], dlog_std[3], pg, v, clip_frac, kl) live in LDS, in the padding of the w2 image
+    // (pitch kP2 = 20, 16 used): lane l of wave w owns float 16 + w of its row in chain k.  In registers they were the
+    // first thing the allocator parked in scratch (11 reload-add-spill round trips per tile).
+    static_assert(kP2 - 16 >= kWaves && 2 * B2 * B1 >= 11 && Im::oW2T == Im::oW2 + Im::kW2, "stat slots fit into the padding of the w2 and w2t images (contiguous)");
+    int o_stat = Im::oW2 + lane * kP2 + 16 + wave;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) lds[o_stat + k * 64 * kP2] = 0.0f;
 
     // ---- accumulators of the launch -----------------------------------------------------------------------------------
-    f32x16 acc_w2[B2][B1], acc_w1[B1], acc_w3[B2], acc_b2[B2];
+    f32x16 acc_w2[B2][B1], acc_w1[B1];
+    float f_w3[4] = {0.0f, 0.0f, 0.0f, 0.0f}, f_b2 = 0.0f;   // lane = layer-2 feature: dW3^T[lane][0..3], db2[lane]
+    int q_fr = (stage0 + lane * kPitch) >> 2;                // row `lane` of the transposed a2 / delta2 tile
+    int q_g = (stage0 + Im::sG) >> 2;                        // g's four rows (the same address in every lane: LDS broadcast)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
 #pragma unroll
         for (int mb = 0; mb < B2; ++mb) {
-            acc_w3[mb][r] = 0.0f;
-            acc_b2[mb][r] = 0.0f;
 #pragma unroll
             for (int ib = 0; ib < B1; ++ib) acc_w2[mb][ib][r] = 0.0f;
         }
 #pragma unroll
         for (int ib = 0; ib < B1; ++ib) acc_w1[ib][r] = 0.0f;
     }
-    float sc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // db3[4], dlog_std[3], pg, v, clip_frac, kl
 
     const int64_t n_tiles = (a.n + 31) >> 5;
 #pragma unroll 1
@@ -193,6 +238,19 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         const bool live = si < a.n;
         const int64_t row = live ? (a.index ? a.index[si] : si) : 0;
 
+        R6U_OPAQUE(q_w3);
+        R6U_OPAQUE(q_b2);
+        R6U_OPAQUE(o_tw);
+        R6U_OPAQUE(q_tr);
+        R6U_OPAQUE(o_stat);
+        R6U_OPAQUE(q_fr);
+        R6U_OPAQUE(q_g);
+        const int o_fr = q_fr << 2, o_g = q_g << 2;
+        const float* w3_base = lds + (q_w3 << 2);
+        const float* b2_base = lds + (q_b2 << 2);
+        float* tw_base = lds + o_tw;
+        const float* tr_base = lds + (q_tr << 2);
+        float* stat_base = lds + o_stat;
         // ---- x: this lane's 8 features k = 2s + h of its sample (B operand of layer 1), bias column k == OD = 1 --------
         float xk[8];
 #pragma unroll
@@ -205,6 +263,19 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
         }
 
+        wave_sync();   // the previous tile's readers of the staging area are done
+#pragma unroll
+        for (int s = 0; s < 8; ++s) tw_base[Im::sX + (2 * s - 3 * h) * kPitch] = xk[s];   // row 2s + h (tw_base sits at row 4h)
+        // the scalars of the loss: fetched now, needed after layer 2 (one wave per SIMD: nobody hides a gather's latency later)
+        float act0 = 0.0f, act1 = 0.0f, act2 = 0.0f, olp = 0.0f, advv = 0.0f, retv = 0.0f;
+        if (live) {
+            act0 = a.action[3 * row + 0];
+            act1 = a.action[3 * row + 1];
+            act2 = a.action[3 * row + 2];
+            olp = a.old_logp[row];
+            advv = a.adv[row];
+            retv = a.ret[row];
+        }
 #ifdef R6U_STAMPS
         uint64_t mark_ = wall_clock64();
 #endif
@@ -221,25 +292,32 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             for (int s = 0; s < 8; ++s) z = mfma(wa[s], xk[s], z);
 #pragma unroll
             for (int r = 0; r < 16; ++r) a1[blk][r] = tanh_fast(z[r]);
-            __builtin_amdgcn_sched_barrier(0);   // one chain at a time: operand loads hoisted from later chains would spill, and with
+            R6U_CHAIN_FENCE();   // one chain at a time: operand loads hoisted from later chains would spill, and with
                                                  // one wave per SIMD a scratch access is an exposed memory round trip
         }
         R6U_MARK(0);   // F1
-#pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
+        {   // chains c = mb * B1 + b; the next chain's 16 weights are fetched while this chain runs on the matrix core
+            float wa[2][16];
+            ldv<16>(&lds[Im::oW2 + lane * kP2], wa[0]);
             f32x16 z;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = lds[Im::oB2 + (mb * 2 + h) * 16 + r];
+            for (int c = 0; c < B2 * B1; ++c) {
+                const int mb = c / B1, b = c % B1;
+                if (b == 0) {
+                    float zi[16];
+                    ldv<16>(b2_base + mb * 32, zi);
 #pragma unroll
-            for (int b = 0; b < B1; ++b) {
-                float wa[16];
-                ldv<16>(&lds[Im::oW2 + ((mb * B1 + b) * 64 + lane) * kP2], wa);
+                    for (int r = 0; r < 16; ++r) z[r] = zi[r];
+                }
+                if (c + 1 < B2 * B1) ldv<16>(&lds[Im::oW2 + ((c + 1) * 64 + lane) * kP2], wa[(c + 1) & 1]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z = mfma(wa[r], a1[b][r], z);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 16; ++r) z = mfma(wa[c & 1][r], a1[b][r], z);
+                if (b == B1 - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a2[mb][r] = tanh_fast(z[r]);
+                }
+                R6U_CHAIN_FENCE();
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a2[mb][r] = tanh_fast(z[r]);
         }
         R6U_MARK(1);   // F2
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -247,7 +325,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float* w3 = &lds[Im::oW3 + ((h * B2 + mb) * 16 + r) * 4];
+                const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + (mb * 16 + r) * 4);
                 part[0] = fmaf(w3[0], a2[mb][r], part[0]);
                 part[1] = fmaf(w3[1], a2[mb][r], part[1]);
                 part[2] = fmaf(w3[2], a2[mb][r], part[2]);
@@ -262,62 +340,52 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         // ---- loss and its gradient w.r.t. (mean, value): r6_ppo_loss_grad's formulas, per sample --------------------------
         float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (live) {
-            const float d0 = a.action[3 * row + 0] - m0, d1 = a.action[3 * row + 1] - m1, d2 = a.action[3 * row + 2] - m2;
+            const float d0 = act0 - m0, d1 = act1 - m1, d2 = act2 - m2;
             const float q0 = d0 * d0 * iv0, q1 = d1 * d1 * iv1, q2 = d2 * d2 * iv2;
-            const float logp = -0.5f * (q0 + q1 + q2) - (ls0 + ls1 + ls2) - 2.756815599614018f;
-            const float dl = logp - a.old_logp[row];
+            const float logp = -0.5f * (q0 + q1 + q2) - ls_sum;
+            const float dl = logp - olp;
             const float ratio = __expf(dl);
-            const float A = (a.adv[row] - a_mean) * a_istd;
+            const float A = (advv - a_mean) * a_istd;
             const float s1 = A * ratio, s2 = A * fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip);
             const bool active = !((A > 0.0f && ratio > 1.0f + a.clip) || (A < 0.0f && ratio < 1.0f - a.clip));
             const float g_logp = active ? -s1 * inv_n : 0.0f;
             g[0] = g_logp * d0 * iv0;
             g[1] = g_logp * d1 * iv1;
             g[2] = g_logp * d2 * iv2;
-            const float ve = vv - a.ret[row];
-            g[3] = a.vf_coef * 2.0f * ve * inv_n;
+            const float ve = vv - retv;
+            g[3] = vf2n * ve;
             if (h == 0) {   // each sample is counted once (both lane halves hold it)
-                sc[0] += g[0];
-                sc[1] += g[1];
-                sc[2] += g[2];
-                sc[3] += g[3];
-                sc[4] += g_logp * (q0 - 1.0f);
-                sc[5] += g_logp * (q1 - 1.0f);
-                sc[6] += g_logp * (q2 - 1.0f);
-                sc[7] += -fminf(s1, s2);
-                sc[8] += ve * ve;
-                sc[9] += (fabsf(ratio - 1.0f) > a.clip) ? 1.0f : 0.0f;
-                sc[10] += (ratio - 1.0f) - dl;
+                const float add[11] = {g[0], g[1], g[2], g[3], g_logp * (q0 - 1.0f), g_logp * (q1 - 1.0f), g_logp * (q2 - 1.0f),
+                                       -fminf(s1, s2), ve * ve, (fabsf(ratio - 1.0f) > a.clip) ? 1.0f : 0.0f, (ratio - 1.0f) - dl};
+                float cur[11];
+#pragma unroll
+                for (int k = 0; k < 11; ++k) cur[k] = stat_base[k * 64 * kP2];
+#pragma unroll
+                for (int k = 0; k < 11; ++k) stat_base[k * 64 * kP2] = cur[k] + add[k];
             }
         }
 
         R6U_MARK(2);   // heads + loss
         // ---- dW3^T[f][o] += sum_s a2[f][s] g[o][s]: a2 and g transposed through LDS, samples on K ---------------------------
-        wave_sync();   // the previous tile's readers of the staging area are done
 #pragma unroll
         for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[Im::sT2 + (mb * 32 + rowmap(r, h)) * kPitch + pcol] = a2[mb][r];
+            for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = a2[mb][r];
         }
         if (h == 0) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) st[Im::sG + o * kPitch + pcol] = g[o];
+            for (int o = 0; o < 4; ++o) tw_base[Im::sG + o * kPitch] = g[o];
         }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) st[Im::sX + (2 * s + h) * kPitch + pcol] = xk[s];
         wave_sync();
-        {
-            float bg[16];
-            ldv<16>(&st[Im::sG + (col & 3) * kPitch + hoff], bg);
+        // On the VALU, lane = feature (H2 = 64 rows of the tile, one per lane): 128 FMAs -- as an MFMA product with 4 useful
+        // columns of 32 this took 32 matrix instructions (2048+ cycles) and two accumulator blocks.
 #pragma unroll
-            for (int s = 0; s < 16; ++s) bg[s] = (col < 4) ? bg[s] : 0.0f;
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
 #pragma unroll
-            for (int mb = 0; mb < B2; ++mb) {
-                float ta[16];
-                ldv<16>(&st[Im::sT2 + (mb * 32 + col) * kPitch + hoff], ta);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc_w3[mb] = mfma(ta[s], bg[s], acc_w3[mb]);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int o = 0; o < 4; ++o) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + o_g + o * kPitch + 4 * q);
+                f_w3[o] = fmaf(av[0], gv[0], fmaf(av[1], gv[1], fmaf(av[2], gv[2], fmaf(av[3], gv[3], f_w3[o]))));
             }
         }
 
@@ -328,7 +396,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float* w3 = &lds[Im::oW3 + ((h * B2 + mb) * 16 + r) * 4];
+                const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + (mb * 16 + r) * 4);
                 const float up = fmaf(w3[0], g[0], fmaf(w3[1], g[1], fmaf(w3[2], g[2], w3[3] * g[3])));
                 d2[mb][r] = up * fmaf(-a2[mb][r], a2[mb][r], 1.0f);
             }
@@ -337,18 +405,21 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
         for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[Im::sT2 + (mb * 32 + rowmap(r, h)) * kPitch + pcol] = d2[mb][r];
+            for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = d2[mb][r];
         }
         wave_sync();
-        // db2[f] += sum_s delta2[f][s]: B = a column of ones (n == 0)
-        const float ones0 = (col == 0) ? 1.0f : 0.0f;
+        // db2[f] += sum_s delta2[f][s]: lane = feature again, a row sum
+        {
+            float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
-            float ta[16];
-            ldv<16>(&st[Im::sT2 + (mb * 32 + col) * kPitch + hoff], ta);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc_b2[mb] = mfma(ta[s], ones0, acc_b2[mb]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
+                rs[0] += dv[0];
+                rs[1] += dv[1];
+                rs[2] += dv[2];
+                rs[3] += dv[3];
+            }
+            f_b2 += (rs[0] + rs[1]) + (rs[2] + rs[3]);
         }
 
         R6U_MARK(4);   // delta2 + db2
@@ -357,49 +428,50 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         for (int ib = 0; ib < B1; ++ib) {
             wave_sync();   // the block buffer's previous readers are done
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[Im::sBlk + rowmap(r, h) * kPitch + pcol] = a1[ib][r];
+            for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = a1[ib][r];
             wave_sync();
             // dW2[f2][i] += sum_s delta2[f2][s] a1[i][s]
+            // Each chain's operands are fetched while the chain before it runs (static_assert: B2 == 2).
+            float op[2][16], bx[16];
             {
                 float ba[16];
-                ldv<16>(&st[Im::sBlk + col * kPitch + hoff], ba);
+                ldv<16>(tr_base + Im::sBlk, ba);
+                ldv<16>(tr_base + Im::sT2, op[0]);
+                ldv<16>(tr_base + Im::sT2 + 32 * kPitch, op[1]);
 #pragma unroll
-                for (int mb = 0; mb < B2; ++mb) {
-                    float ta[16];
-                    ldv<16>(&st[Im::sT2 + (mb * 32 + col) * kPitch + hoff], ta);
+                for (int s = 0; s < 16; ++s) acc_w2[0][ib] = mfma(op[0][s], ba[s], acc_w2[0][ib]);
+                R6U_CHAIN_FENCE();
+                ldv<16>(&lds[Im::oW2T + ((ib * B2 + 0) * 64 + lane) * kP2], op[0]);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc_w2[mb][ib] = mfma(ta[s], ba[s], acc_w2[mb][ib]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int s = 0; s < 16; ++s) acc_w2[1][ib] = mfma(op[1][s], ba[s], acc_w2[1][ib]);
+                R6U_CHAIN_FENCE();
             }
             R6U_MARK(5);   // G2
             // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
             f32x16 d1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+            ldv<16>(&lds[Im::oW2T + ((ib * B2 + 1) * 64 + lane) * kP2], op[1]);
 #pragma unroll
-            for (int c = 0; c < B2; ++c) {
-                float wa[16];
-                ldv<16>(&lds[Im::oW2T + ((ib * B2 + c) * 64 + lane) * kP2], wa);
+            for (int r = 0; r < 16; ++r) d1 = mfma(op[0][r], d2[0][r], d1);
+            R6U_CHAIN_FENCE();
+            ldv<16>(tr_base + Im::sX - col * kPitch + (col & 15) * kPitch, bx);   // x's row (col & 15): B of dW1 below
 #pragma unroll
-                for (int r = 0; r < 16; ++r) d1 = mfma(wa[r], d2[c][r], d1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int r = 0; r < 16; ++r) d1 = mfma(op[1][r], d2[1][r], d1);
+            R6U_CHAIN_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ib][r], a1[ib][r], 1.0f);
             R6U_MARK(6);   // B2
             wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[Im::sBlk + rowmap(r, h) * kPitch + pcol] = d1[r];
+            for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
             wave_sync();
             // dW1[i][k] += sum_s delta1[i][s] x[k][s]   (k == OD: db1, through x's column of ones)
             {
-                float bx[16], ta[16];
-                ldv<16>(&st[Im::sX + (col & 15) * kPitch + hoff], bx);
-                ldv<16>(&st[Im::sBlk + col * kPitch + hoff], ta);
+                ldv<16>(tr_base + Im::sBlk, op[0]);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc_w1[ib] = mfma(ta[s], (col < 16) ? bx[s] : 0.0f, acc_w1[ib]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int s = 0; s < 16; ++s) acc_w1[ib] = mfma(op[0][s], (col < 16) ? bx[s] : 0.0f, acc_w1[ib]);
+                R6U_CHAIN_FENCE();
             }
             R6U_MARK(7);   // G1
         }
@@ -409,6 +481,9 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #ifdef R6U_STAMPS
     const uint64_t ts2 = wall_clock64();
 #endif
+    float sc[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) sc[k] = lds[o_stat + k * 64 * kP2];
     __syncthreads();
     float* reds = lds;                             // [kWaves][kScalars]: the weight images are not needed any more
     float* out = partial + (int64_t)blockIdx.x * kPartial;
@@ -422,7 +497,15 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     __syncthreads();
     if (tid < kScalars) reds[tid] = (tid < 11) ? (reds[tid] + reds[kScalars + tid]) + (reds[2 * kScalars + tid] + reds[3 * kScalars + tid]) : 0.0f;
     __syncthreads();
-    if (tid < kScalars) out[kNumBlocks * 1024 + tid] = reds[tid];
+    if (tid < kScalars) out[kOffScal + tid] = reds[tid];
+    {   // per-feature sums: [kWaves][kFeat] behind the scalars, then one thread per entry adds the four waves
+        float* fr = lds + kWaves * kScalars;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) fr[wave * kFeat + o * 64 + lane] = f_w3[o];
+        fr[wave * kFeat + 4 * 64 + lane] = f_b2;
+        __syncthreads();
+        for (int e = tid; e < kFeat; e += kBlock) out[kOffFeat + e] = (fr[e] + fr[kFeat + e]) + (fr[2 * kFeat + e] + fr[3 * kFeat + e]);
+    }
     // Blocks: every wave writes its accumulator block to its own LDS slab in canonical [m][n] order (the staging areas are
     // free now: four blocks fit into each), then the workgroup adds the four slabs in a fixed order -- no atomics (a float
     // atomicAdd on LDS compiles to a compare-and-swap loop without unsafe-fp-atomics: 5.8 us per block, measured), and the
@@ -452,17 +535,11 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
     for (int ib = 0; ib < B1; ++ib) put(acc_w1[ib], ib);
     drain(B2 * B1, B1);
-#pragma unroll
-    for (int mb = 0; mb < B2; ++mb) {
-        put(acc_w3[mb], mb);
-        put(acc_b2[mb], B2 + mb);
-    }
-    drain(B2 * B1 + B1, 2 * B2);
 #ifdef R6U_STAMPS
     if (tid == 0) {   // 100 MHz ticks: staging, tile loop of wave 0, reduction
-        out[kNumBlocks * 1024 + 12] = (float)(ts1 - ts0);
-        out[kNumBlocks * 1024 + 13] = (float)(ts2 - ts1);
-        out[kNumBlocks * 1024 + 14] = (float)(wall_clock64() - ts2);
+        out[kOffScal + 12] = (float)(ts1 - ts0);
+        out[kOffScal + 13] = (float)(ts2 - ts1);
+        out[kOffScal + 14] = (float)(wall_clock64() - ts2);
     }
 #endif
 }
@@ -497,20 +574,18 @@ __global__ __launch_bounds__(256) void ppo_grad_reduce_kernel(const float* __res
         if (blk < B2 * B1) {                       // dW2[mb*32 + m][ib*32 + n]
             const int mb = blk / B1, ib = blk % B1;
             gr.w2[(mb * 32 + m) * H1 + ib * 32 + nn] = v;
-        } else if (blk < B2 * B1 + B1) {           // dW1[ib*32 + m][k = n], k == OD: db1
+        } else {                                   // dW1[ib*32 + m][k = n], k == OD: db1
             const int ib = blk - B2 * B1;
             if (nn < OD) gr.w1[(ib * 32 + m) * OD + nn] = v;
             else if (nn == OD) gr.b1[ib * 32 + m] = v;
-        } else if (blk < B2 * B1 + B1 + B2) {      // dW3^T[mb*32 + m][o = n]
-            const int mb = blk - (B2 * B1 + B1);
-            if (nn < 3) gr.pi_w3[nn * H2 + mb * 32 + m] = v;
-            else if (nn == 3) gr.vf_w3[mb * 32 + m] = v;
-        } else {                                   // db2[mb*32 + m] in column 0
-            const int mb = blk - (B2 * B1 + B1 + B2);
-            if (nn == 0) gr.b2[mb * 32 + m] = v;
         }
+    } else if (e < kOffScal) {                     // per-feature sums: dW3^T[f][o] (o < 3: action head, o == 3: value head), db2[f]
+        const int o = (e - kOffFeat) >> 6, f = (e - kOffFeat) & 63;
+        if (o < 3) gr.pi_w3[o * H2 + f] = v;
+        else if (o == 3) gr.vf_w3[f] = v;
+        else gr.b2[f] = v;
     } else {
-        const int k = e - kNumBlocks * 1024;
+        const int k = e - kOffScal;
         if (k < 3) gr.pi_b3[k] = v;
         else if (k == 3) gr.vf_b3[0] = v;
         else if (k < 7) gr.log_std[k - 4] = v - ent_coef;   // entropy = sum_i (0.5 + 0.5 ln 2pi + log_std_i): d(ent_coef * -ent) = -ent_coef

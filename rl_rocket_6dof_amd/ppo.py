@@ -517,20 +517,31 @@ class PPO:
                 acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
                                     ((ratio - 1) - (logp - old_logp[mb])).mean()])
 
-    def _graphed_step(self, flat, bs):
-        """The minibatch step captured once into a HIP graph (static index / stats buffers) and replayed: at
-        minibatches of <= 2^17 samples the ~250 kernels of a step are launch-bound in eager mode (2.1 ms per
-        step at 65 536 samples against ~0.4 ms of GPU work).  Single-process only (no collective inside)."""
-        key = (bs,) + tuple(t.data_ptr() for t in flat)
+    def _graphed_steps(self, flat, bs, chunk):
+        """``chunk`` consecutive minibatch steps captured once into a HIP graph (static index / stats buffers) and
+        replayed: at minibatches of <= 2^17 samples the ~250 kernels of a torch step are launch-bound in eager mode
+        (2.1 ms per step at 65 536 samples against ~0.4 ms of GPU work), and with the fused kernels (4 launches,
+        ~0.09 ms per step) even one index copy + one graph launch per STEP is a fifth of the time -- so a whole
+        epoch's steps (up to 32) share one replay and one copy of the permutation.  Single-process only (no
+        collective inside)."""
+        key = (bs, chunk) + tuple(t.data_ptr() for t in flat)
         if self._graph is not None and self._graph_key == key:
             return self._graph
-        self._mb_idx = torch.zeros(bs, dtype=torch.int64, device=self.device)
+        self._mb_idx = torch.zeros(chunk * bs, dtype=torch.int64, device=self.device)
         self._acc = torch.zeros(5, dtype=torch.float32, device=self.device)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self._minibatch_step(self._mb_idx, flat, self._acc)
+            for c in range(chunk):
+                self._minibatch_step(self._mb_idx[c * bs:(c + 1) * bs], flat, self._acc)
         self._graph_key = key
         return self._graph
+
+    def _graph_chunk(self, steps: int) -> int:
+        """Steps per graph replay: the largest divisor of the epoch's step count up to 32 (fused kernels only: a torch
+        step is ~250 nodes and already amortises its launch)."""
+        if self.fused_update is None:
+            return 1
+        return max(c for c in range(1, min(steps, 32) + 1) if steps % c == 0)
 
     def train(self) -> Dict[str, float]:
         cfg = self.cfg
@@ -543,18 +554,25 @@ class PPO:
         use_graph = cfg.graph_update and self.device.type == "cuda" and self.world == 1 and bs <= (1 << 17)
         acc = torch.zeros(len(keys), dtype=torch.float32, device=self.device)   # summed on the device: no per-batch sync
         n_batches = 0
+        steps = self._steps_per_epoch                              # the same count on every rank (agreed in __init__)
+        chunk = self._graph_chunk(steps) if use_graph else 1
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(total, device=self.device, generator=self.gen)
-            for s in range(0, self._steps_per_epoch * bs, bs):     # the same count on every rank (agreed in __init__)
-                mb = perm[s:s + bs]
-                if use_graph and self._eager_steps >= 3:      # the first steps run eagerly (allocator / Adam state warm-up)
-                    g = self._graphed_step(flat, bs)
-                    self._mb_idx.copy_(mb)
+            s = 0
+            while s < steps:
+                # the first steps run eagerly (allocator / Adam state warm-up), and so does the rest of that epoch when
+                # it is shorter than a chunk
+                if use_graph and self._eager_steps >= 3 and s + chunk <= steps:
+                    g = self._graphed_steps(flat, bs, chunk)
+                    self._mb_idx.copy_(perm[s * bs:(s + chunk) * bs])
                     g.replay()
+                    s += chunk
+                    n_batches += chunk
                 else:
-                    self._minibatch_step(mb, flat, acc)
+                    self._minibatch_step(perm[s * bs:(s + 1) * bs], flat, acc)
                     self._eager_steps += 1
-                n_batches += 1
+                    s += 1
+                    n_batches += 1
         if use_graph and self._graph is not None:
             acc += self._acc
             self._acc.zero_()
