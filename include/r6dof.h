@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define R6_ABI_VERSION 4
+#define R6_ABI_VERSION 5
 #define R6_STATE_DIM 14
 #define R6_ACTION_DIM 3
 #define R6_NUM_TERMS 8 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
@@ -137,6 +137,10 @@ typedef struct R6Buffers {
                                        finished episodes (see R6_STAT_*): accumulated with LDS float
                                        atomics inside a workgroup, then added to the workgroup's own row
                                        (no global atomics); the caller sums the rows */
+    const uint64_t *step_base; /* [1]  in (device memory) or NULL: added to the `step_index` argument where the reset
+                                       RNG is keyed.  A launch recorded into a HIP graph carries its by-value arguments
+                                       for ever; with the counter's base in device memory a replayed rollout still draws
+                                       fresh initial conditions (the caller advances *step_base between replays) */
 } R6Buffers;
 
 int r6_abi_version(void);
@@ -230,10 +234,26 @@ size_t r6_policy_net_size(void); /* sizeof(R6PolicyNet) */
  * does not depend on sharding; `deterministic` != 0 returns the mean action (`model.predict(...,
  * deterministic=True)`, montecarlo_script.py).  fp32-accurate arithmetic on the matrix cores: every fp32 operand is
  * split into an f16 hi + lo pair (v_mfma_f32_32x32x16_f16, three products per K-step, fp32 accumulation; agrees
- * with torch fp32 to 2e-5). */
+ * with torch fp32 to 2e-5).
+ *   step_base (device, [1], or NULL) is added to step_index inside the kernel (see R6Buffers.step_base: graph replays).
+ *   row_flags [n] / flag_mask: when row_flags != NULL only 32-row tiles holding a row with (row_flags[i] & flag_mask) != 0
+ *   are evaluated and written, the others are skipped without touching their outputs -- V(terminal observation) for the
+ *   envs a TimeLimit truncated in this step (row_flags = R6Buffers.flags, flag_mask = R6_FLAG_TRUNCATED), decided on the
+ *   device: a rollout loop needs no host round trip to know whether any env was truncated. */
 int r6_policy_act(const R6PolicyNet *net, const float *obs, int64_t n, float *action, float *raw_action,
-                  float *value, float *logp, uint64_t seed, uint64_t step_index, uint64_t env_offset,
-                  int deterministic, void *stream);
+                  float *value, float *logp, uint64_t seed, uint64_t step_index, const uint64_t *step_base,
+                  uint64_t env_offset, int deterministic, const uint8_t *row_flags, int flag_mask, void *stream);
+
+/* SB3 `RolloutBuffer.compute_returns_and_advantage` (GAE(lambda); stable_baselines3/common/buffers.py, called from
+ * OnPolicyAlgorithm.collect_rollouts behind main_6DOF.py:136-139) for T steps of n envs in one launch, one lane per env:
+ *   delta_t = r_t + gamma V_{t+1} (1 - done_t) - V_t,  A_t = delta_t + gamma lambda (1 - done_t) A_{t+1},  ret_t = A_t + V_t
+ * rewards / values / adv / ret: (T, n) float32; dones: (T, n) uint8, done_t = the episode ended AT step t; last_values [n].
+ * Time-limit bootstrap (SB3 adds gamma * V(terminal_observation) to the reward of a truncated step): when flags and
+ * boot_values are given, r_t += gamma * boot_values[t][i] where (flags[t][i] & flag_mask) != 0 -- boot_values entries of
+ * other rows are never read (they may be uninitialised: see r6_policy_act's row_flags). */
+int r6_gae(const float *rewards, const float *values, const uint8_t *dones, const float *last_values, int64_t T, int64_t n,
+           float gamma, float lam, const uint8_t *flags, int flag_mask, const float *boot_values, float *adv, float *ret,
+           void *stream);
 
 /* SB3 1.6 `PPO.train` minibatch loss (stable_baselines3/ppo/ppo.py, the trainer behind main_6DOF.py:107-139) and
  * its gradient with respect to the policy outputs, for n samples in one launch:

@@ -9,12 +9,13 @@ import os
 
 from .params import R6Buffers, R6Params, R6PolicyGrad, R6PolicyNet, R6StepK
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad",
-           "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad", "r6_minibatch_adv_norm", "r6_adam_clip_step")
+           "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad", "r6_minibatch_adv_norm", "r6_adam_clip_step",
+           "r6_gae")
 
 
 class R6Error(RuntimeError):
@@ -53,7 +54,7 @@ def load(path: str | None = None):
     lib.r6_sim_step.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
     lib.r6_rhs.argtypes = [C.POINTER(R6Params), vp, vp, vp, vp, i64, i64, vp]
     lib.r6_policy_net_size.restype = C.c_size_t
-    lib.r6_policy_act.argtypes = [C.POINTER(R6PolicyNet), vp, i64, vp, vp, vp, vp, u64, u64, u64, C.c_int, vp]
+    lib.r6_policy_act.argtypes = [C.POINTER(R6PolicyNet), vp, i64, vp, vp, vp, vp, u64, u64, vp, u64, C.c_int, vp, C.c_int, vp]
     f32 = C.c_float
     lib.r6_ppo_loss_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
     lib.r6_policy_grad_size.restype = C.c_size_t
@@ -65,6 +66,8 @@ def load(path: str | None = None):
     lib.r6_minibatch_adv_norm.restype = C.c_int
     lib.r6_adam_clip_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, vp, f32, f32, f32, vp, i64, i64, f32, vp]
     lib.r6_adam_clip_step.restype = C.c_int
+    lib.r6_gae.argtypes = [vp, vp, vp, vp, i64, i64, f32, f32, vp, C.c_int, vp, vp, vp, vp]
+    lib.r6_gae.restype = C.c_int
     if lib.r6_policy_grad_size() != C.sizeof(R6PolicyGrad):
         raise ImportError("R6PolicyGrad layout mismatch between params.py and libr6dof.so: rebuild")
     for name in ("r6_step", "r6_step_k", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):

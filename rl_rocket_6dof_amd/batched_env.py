@@ -196,6 +196,7 @@ class BatchedRocket6DOF(VecEnv):
         self.stats = torch.zeros((MAX_BLOCKS, NUM_STATS), dtype=torch.float64, device=dev) if track else None   # float64: counts stay exact
 
         self._buf = R6Buffers()
+        self._step_base = None
         self._fill_buffers(self._act)
         self._step_count = 0     # global step counter (keys the auto-reset RNG), first step = 1
         self._reset_count = 0
@@ -260,6 +261,57 @@ class BatchedRocket6DOF(VecEnv):
                                   self.env_offset, self._stream())
         _lib.check(rc, "r6_step", self.lib)
         self._pending = a   # keeps the action tensor alive until step_wait
+
+    def set_step_base(self, base: Optional[torch.Tensor]) -> None:
+        """``R6Buffers.step_base``: an int64 device scalar that the kernels ADD to the step counter keying the reset RNG.
+        A step recorded into a HIP graph replays with the host counter it was captured with; the caller moves ``base`` on
+        between replays (``base += steps per replay``, itself a node of the graph) and finished episodes keep drawing
+        fresh initial conditions.  ``None`` detaches it."""
+        if base is not None and (base.dtype != torch.int64 or base.device != self.device or base.numel() != 1):
+            raise ValueError("step base must be an int64 scalar tensor on the env's device")
+        self._step_base = base          # keeps the tensor alive
+        self._buf.step_base = _ptr(base)
+
+    def step_into(self, actions: torch.Tensor, *, obs: Optional[torch.Tensor] = None, reward: Optional[torch.Tensor] = None,
+                  done: Optional[torch.Tensor] = None, flags: Optional[torch.Tensor] = None,
+                  final_obs: Optional[torch.Tensor] = None) -> None:
+        """One env step whose outputs go straight into the caller's tensors (a rollout buffer's rows for this time step)
+        instead of the env's own ``obs`` / ``reward`` / ``done`` / ``flags`` / ``final_obs`` -- no copy kernels in a rollout
+        loop, and nothing but the launch itself when the loop is recorded into a HIP graph.  Outputs that are not given
+        go to the env's buffers as in ``step``.  ``done`` / ``flags``: uint8; every tensor contiguous on the env's device,
+        ``obs`` / ``final_obs`` 16-byte aligned.  Device tensors in, nothing returned, no ``infos``."""
+        n, od = self.num_envs, self.obs_dim
+        if not (torch.is_tensor(actions) and actions.device == self.device and actions.dtype == torch.float32
+                and actions.is_contiguous() and tuple(actions.shape) == (n, ACTION_DIM) and actions.data_ptr() % 16 == 0):
+            raise ValueError(f"step_into needs a contiguous, 16-byte aligned float32 ({n}, {ACTION_DIM}) action tensor on {self.device}")
+
+        def chk(t, name, shape, dtype, align):
+            if t is None:
+                return None
+            if t.device != self.device or t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous() or t.data_ptr() % align:
+                raise ValueError(f"step_into: {name} must be a contiguous {dtype} {shape} tensor on {self.device}, {align}-byte aligned")
+            return t
+
+        b = R6Buffers.from_buffer_copy(self._buf)
+        b.action = _ptr(actions)
+        if chk(obs, "obs", (n, od), torch.float32, 16) is not None:
+            b.obs = _ptr(obs)
+        if chk(reward, "reward", (n,), torch.float32, 4) is not None:
+            b.reward = _ptr(reward)
+        if chk(done, "done", (n,), torch.uint8, 1) is not None:
+            b.done = _ptr(done)
+        if chk(flags, "flags", (n,), torch.uint8, 1) is not None:
+            if self.flags is None:
+                raise ValueError("step_into: flags need an env built with record_flags=True")
+            b.flags = _ptr(flags)
+        if chk(final_obs, "final_obs", (n, od), torch.float32, 16) is not None:
+            if self.final_obs is None:
+                raise ValueError("step_into: final_obs needs an env that records terminal observations")
+            b.final_obs = _ptr(final_obs)
+        self._step_count += 1
+        with torch.cuda.device(self.device):
+            rc = self.lib.r6_step(C.byref(self.params), C.byref(b), self._seed, self._step_count, self.env_offset, self._stream())
+        _lib.check(rc, "r6_step", self.lib)
 
     def step_wait(self):
         self._pending = None

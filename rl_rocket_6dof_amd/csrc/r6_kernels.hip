@@ -121,7 +121,8 @@ __device__ __forceinline__ void reset_env_global(const R6Params& p, const R6Buff
                                                  uint64_t step_index, uint64_t env_offset) {
     const int64_t ld = b.ld;
     float ic[R6_STATE_DIM];
-    sample_ic(p, seed, env_offset + (uint64_t)i, step_index, ic);
+    // R6Buffers.step_base: the device-resident part of the step counter (graph replays); read on this rare path only
+    sample_ic(p, seed, env_offset + (uint64_t)i, step_index + (b.step_base ? *b.step_base : (uint64_t)0), ic);
 #pragma unroll
     for (int j = 0; j < R6_STATE_DIM; ++j) b.state[j * ld + i] = ic[j];
     b.epconst[i] = ic[13];
@@ -786,7 +787,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                         if (b.fin_length) b.fin_length[(int64_t)k * sk.fin_stride + i] = ep_step;
                     }
                     float ic[R6_STATE_DIM];
-                    sample_ic(load_params(), seed, env_offset + (uint64_t)i, step_index + (uint64_t)k, ic);
+                    sample_ic(load_params(), seed, env_offset + (uint64_t)i,
+                              step_index + (uint64_t)k + (b.step_base ? *b.step_base : (uint64_t)0), ic);
 #pragma unroll
                     for (int j = 0; j < kDyn; ++j) y[j] = ic[j];
                     mass = m0 = ic[13];

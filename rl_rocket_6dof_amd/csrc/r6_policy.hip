@@ -126,8 +126,11 @@ template <int H1, int H2, int OD>
 __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_WAVES64) void policy_act_kernel(const R6PolicyNet net, const float* __restrict__ obs, const int64_t n,
                                                             float* __restrict__ action, float* __restrict__ raw_action,
                                                             float* __restrict__ value, float* __restrict__ logp,
-                                                            const uint64_t seed, const uint64_t step_index,
-                                                            const uint64_t env_offset, const int deterministic) {
+                                                            const uint64_t seed, const uint64_t step_index_arg,
+                                                            const uint64_t* __restrict__ step_base,
+                                                            const uint64_t env_offset, const int deterministic,
+                                                            const uint8_t* __restrict__ row_flags, const int flag_mask) {
+    const uint64_t step_index = step_index_arg + (step_base ? *step_base : (uint64_t)0);
     using Im = Image<H1, H2>;
     constexpr int kBlock = Shape<H1>::kBlock, kWaves = Shape<H1>::kWaves;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -220,6 +223,10 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
         const bool live = env < n;
         const Split xs = split8(xn);
         load_x(t + nw, xn);
+        if (row_flags) {   // masked evaluation: a tile none of whose rows is wanted is skipped, outputs untouched
+            const bool want = live && (row_flags[env] & flag_mask) != 0;
+            if (__ballot(want) == 0) continue;
+        }
 
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // this lane half's share of (mean0, mean1, mean2, value)
         // one network at a time (rolled): the two share nothing but x[], and unrolled the scheduler
@@ -356,7 +363,8 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
 
 template <int H1, int H2, int OD>
 int launch(const R6PolicyNet& net, const float* obs, int64_t n, float* action, float* raw_action, float* value, float* logp,
-           uint64_t seed, uint64_t step_index, uint64_t env_offset, int deterministic, hipStream_t s) {
+           uint64_t seed, uint64_t step_index, const uint64_t* step_base, uint64_t env_offset, int deterministic,
+           const uint8_t* row_flags, int flag_mask, hipStream_t s) {
     auto kernel = policy_act_kernel<H1, H2, OD>;
     constexpr int kBlock = Shape<H1>::kBlock, kWaves = Shape<H1>::kWaves;
     constexpr size_t lds_bytes = sizeof(float) * Image<H1, H2>::kTotalFloats;
@@ -371,15 +379,24 @@ int launch(const R6PolicyNet& net, const float* obs, int64_t n, float* action, f
         }
         configured[di].store(dev == di, std::memory_order_relaxed);   // devices beyond the table are configured every call
     }
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-    (void)hipGetLastError();
+    // queried once per (function, device): a launch recorded into a HIP graph should issue nothing but the launch
+    static std::atomic<int> resident[16];   // (per_cu << 16) | cus, 0 = not known yet
+    int packed = (dev == di) ? resident[di].load(std::memory_order_relaxed) : 0;
+    if (packed == 0) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        (void)hipGetLastError();
+        packed = (per_cu << 16) | (cus & 0xFFFF);
+        if (dev == di) resident[di].store(packed, std::memory_order_relaxed);
+    }
+    per_cu = packed >> 16;
+    cus = packed & 0xFFFF;
     if (std::getenv("R6_DEBUG")) std::fprintf(stderr, "[r6_policy_act] H1=%d H2=%d block=%d lds=%zu B resident/CU=%d CUs=%d\n", H1, H2, kBlock, lds_bytes, per_cu, cus);
     const int64_t n_tiles = (n + 31) / 32;
     int64_t blocks = (n_tiles + kWaves - 1) / kWaves;
     if (blocks > (int64_t)per_cu * cus) blocks = (int64_t)per_cu * cus;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, net, obs, n, action, raw_action, value, logp,
-                       seed, step_index, env_offset, deterministic);
+                       seed, step_index, step_base, env_offset, deterministic, row_flags, flag_mask);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         r6_internal_set_error(hipGetErrorString(e));
@@ -391,8 +408,8 @@ int launch(const R6PolicyNet& net, const float* obs, int64_t n, float* action, f
 }  // namespace r6p
 
 extern "C" int r6_policy_act(const R6PolicyNet* net, const float* obs, int64_t n, float* action, float* raw_action,
-                             float* value, float* logp, uint64_t seed, uint64_t step_index, uint64_t env_offset,
-                             int deterministic, void* stream) {
+                             float* value, float* logp, uint64_t seed, uint64_t step_index, const uint64_t* step_base,
+                             uint64_t env_offset, int deterministic, const uint8_t* row_flags, int flag_mask, void* stream) {
     if (!net || !obs || !action) {
         r6_internal_set_error("r6_policy_act: net, obs and action are required");
         return R6_E_BADARG;
@@ -414,7 +431,8 @@ extern "C" int r6_policy_act(const R6PolicyNet* net, const float* obs, int64_t n
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define R6P_CASE(A, B, D) \
     if (p.hidden1 == A && p.hidden2 == B && p.obs_dim == D) \
-        return r6p::launch<A, B, D>(p, obs, n, action, raw_action, value, logp, seed, step_index, env_offset, deterministic, s);
+        return r6p::launch<A, B, D>(p, obs, n, action, raw_action, value, logp, seed, step_index, step_base, env_offset, deterministic, \
+                                    row_flags, flag_mask, s);
     R6P_CASE(64, 64, 14)
     R6P_CASE(64, 64, 13)
     R6P_CASE(128, 64, 14)

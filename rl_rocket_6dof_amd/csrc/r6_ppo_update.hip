@@ -684,6 +684,32 @@ __global__ __launch_bounds__(64) void adv_norm_final_kernel(const double* __rest
     }
 }
 
+// GAE(lambda) of a rollout, one lane per env walking its T steps backwards (r6_gae; SB3 RolloutBuffer.compute_returns_and_advantage).
+// The recurrence is serial in t but the loads are not: the unrolled loop keeps eight steps of (reward, value, done) in flight.
+__global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
+                                                   const uint8_t* __restrict__ dones, const float* __restrict__ last_values, const int64_t T,
+                                                   const int64_t n, const float gamma, const float lam, const uint8_t* __restrict__ flags,
+                                                   const int flag_mask, const float* __restrict__ boot, float* __restrict__ adv,
+                                                   float* __restrict__ ret) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float next_v = last_values[i], last = 0.0f;
+    const bool tl = flags != nullptr && boot != nullptr;
+#pragma unroll 8
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const int64_t e = t * n + i;
+        float r = rewards[e];
+        const float v = values[e];
+        const float nonterm = dones[e] ? 0.0f : 1.0f;
+        if (tl && (flags[e] & flag_mask)) r = fmaf(gamma, boot[e], r);   // time-limit bootstrap: gamma * V(terminal observation)
+        const float delta = fmaf(gamma * next_v, nonterm, r) - v;
+        last = fmaf(gamma * lam * nonterm, last, delta);
+        adv[e] = last;
+        ret[e] = last + v;
+        next_v = v;
+    }
+}
+
 // torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() (SB3 1.6's optimiser step:
 // max_grad_norm 0.5, Adam eps 1e-5) for a policy whose parameters, gradients and Adam moments are flat arrays: one
 // workgroup, one launch instead of ~25 (per-tensor norms, the norm of norms, the scale, three multi-tensor Adam kernels,
@@ -756,6 +782,24 @@ extern "C" int r6_minibatch_adv_norm(const float* adv, const int64_t* index, int
     if (blocks > r6u::kNormBlocks) blocks = r6u::kNormBlocks;
     hipLaunchKernelGGL(r6u::adv_norm_partial_kernel, dim3(blocks), dim3(256), 0, s, adv, index, n, scratch);
     hipLaunchKernelGGL(r6u::adv_norm_final_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, n, out2);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        r6_internal_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+extern "C" int r6_gae(const float* rewards, const float* values, const uint8_t* dones, const float* last_values, int64_t T, int64_t n,
+                      float gamma, float lam, const uint8_t* flags, int flag_mask, const float* boot_values, float* adv, float* ret,
+                      void* stream) {
+    if (!rewards || !values || !dones || !last_values || !adv || !ret || T < 0 || n < 0) {
+        r6_internal_set_error("r6_gae: rewards, values, dones, last_values, adv and ret are required");
+        return R6_E_BADARG;
+    }
+    if (T == 0 || n == 0) return 0;
+    hipLaunchKernelGGL(r6u::gae_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rewards, values, dones,
+                       last_values, T, n, gamma, lam, flags, flag_mask, boot_values, adv, ret);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         r6_internal_set_error(hipGetErrorString(e));

@@ -63,6 +63,7 @@ class R6Buffers(C.Structure):
         ("reward", C.c_void_p), ("done", C.c_void_p),
         ("flags", C.c_void_p), ("terms", C.c_void_p), ("final_obs", C.c_void_p), ("ep_step", C.c_void_p),
         ("ep_return", C.c_void_p), ("fin_return", C.c_void_p), ("fin_length", C.c_void_p), ("nfev", C.c_void_p), ("stats", C.c_void_p),
+        ("step_base", C.c_void_p),
     ]
 
 

@@ -59,9 +59,13 @@ class FusedActorCritic:
 
     @torch.no_grad()
     def forward(self, obs: torch.Tensor, deterministic: bool = False, step_index: Optional[int] = None,
-                out: Optional[Tuple[torch.Tensor, ...]] = None):
+                out: Optional[Tuple[torch.Tensor, ...]] = None, step_base: Optional[torch.Tensor] = None,
+                row_flags: Optional[torch.Tensor] = None, flag_mask: int = 0):
         """Returns ``(clipped_actions (N,3), raw_actions (N,3), values (N,), log_probs (N,))``.
-        ``step_index`` keys the noise stream (defaults to an internal call counter); ``out`` reuses buffers."""
+        ``step_index`` keys the noise stream (defaults to an internal call counter); ``out`` reuses buffers.
+        ``step_base``: int64 device scalar added to ``step_index`` inside the kernel (a launch replayed from a HIP graph
+        keeps its by-value arguments; the base in device memory moves on).  ``row_flags`` (N,) uint8 + ``flag_mask``:
+        only 32-row tiles with a flagged row are evaluated, the outputs of the others are left untouched."""
         if obs.device != self.device or obs.dtype != torch.float32 or not obs.is_contiguous() or obs.dim() != 2 \
                 or obs.shape[1] != self.obs_dim:
             raise ValueError(f"obs must be a contiguous float32 (N, {self.obs_dim}) tensor on {self.device}")
@@ -73,9 +77,16 @@ class FusedActorCritic:
         self._calls += 1
         step = self._calls if step_index is None else int(step_index)
         net = self._net()
+        if step_base is not None and (step_base.dtype != torch.int64 or step_base.device != self.device or step_base.numel() != 1):
+            raise ValueError("step_base must be an int64 scalar tensor on the policy's device")
+        if row_flags is not None and (row_flags.dtype != torch.uint8 or row_flags.device != self.device
+                                      or row_flags.numel() != n or not row_flags.is_contiguous()):
+            raise ValueError("row_flags must be a contiguous uint8 (N,) tensor on the policy's device")
         with torch.cuda.device(self.device):
             rc = self.lib.r6_policy_act(C.byref(net), obs.data_ptr(), n, act.data_ptr(), raw.data_ptr(), val.data_ptr(),
-                                        logp.data_ptr(), self.seed, step, self.env_offset, int(bool(deterministic)),
+                                        logp.data_ptr(), self.seed, step, None if step_base is None else step_base.data_ptr(),
+                                        self.env_offset, int(bool(deterministic)),
+                                        None if row_flags is None else row_flags.data_ptr(), int(flag_mask),
                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         _lib.check(rc, "r6_policy_act", self.lib)
         return act, raw, val, logp

@@ -23,6 +23,7 @@ the return improves.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence
@@ -62,6 +63,9 @@ class PPOConfig:
     graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
     fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
                                      # net shape is supported and the env is on a GPU; torch modules otherwise
+    graph_rollout: bool = True       # with the fused forward: a whole rollout (n_steps x (policy, env step, time-limit
+                                     # bootstrap) + GAE) is recorded once into a HIP graph and replayed -- three launches
+                                     # per step and no host work; the RNG counters advance through a device-side base
 
 
 class _FusedPPOLoss(torch.autograd.Function):
@@ -368,7 +372,7 @@ class PPO:
         self.buf_logp = torch.zeros((T, n), **f32)
         self.buf_val = torch.zeros((T, n), **f32)
         self.buf_rew = torch.zeros((T, n), **f32)
-        self.buf_done = torch.zeros((T, n), **f32)
+        self.buf_done = torch.zeros((T, n), dtype=torch.uint8, device=self.device)
         self.adv = torch.zeros((T, n), **f32)
         self.ret = torch.zeros((T, n), **f32)
         self._obs = None
@@ -386,6 +390,18 @@ class PPO:
                 self._act_clip = torch.zeros((n, 3), **f32)
                 self._boot_out = (torch.zeros((n, 3), **f32), torch.zeros((n, 3), **f32), torch.zeros((n,), **f32),
                                   torch.zeros((n,), **f32))
+                self._last_val = torch.zeros((n,), **f32)
+                # time-limit bootstrap on the device: per step the truncation flags and V(terminal observation) of the
+                # flagged rows (written by a masked forward, read by r6_gae only where the flag is set)
+                self._time_limit = bool(getattr(env, "max_episode_steps", 0))
+                self.buf_flags = torch.zeros((T, n), dtype=torch.uint8, device=self.device) if self._time_limit else None
+                self.buf_boot = torch.zeros((T, n), **f32) if self._time_limit else None
+                # env outputs land directly in the rollout buffer when its rows are 16-byte aligned (BatchedRocket6DOF.step_into)
+                self._direct = hasattr(env, "step_into") and (n * env.obs_dim) % 4 == 0 and not getattr(env, "numpy_io", False)
+                self._step_base = torch.zeros((), dtype=torch.int64, device=self.device)
+                self._rollout_graph, self._rollouts = None, 0
+                if self._direct:
+                    env.set_step_base(self._step_base)
 
     def _all_reduce(self, t: torch.Tensor, op=None) -> torch.Tensor:
         """Sum (default) over ranks of a small host tensor: through the device for RCCL, on the host for gloo."""
@@ -404,12 +420,73 @@ class PPO:
         return len(lin) == 3 and (lin[0].out_features, lin[1].out_features) in SUPPORTED_ARCHS
 
     # ------------------------------------------------------------------------------------------
+    def _rollout_launches(self):
+        """One rollout + GAE as a fixed sequence of launches with no host decision in it (so it can be recorded into a
+        HIP graph): per step the fused policy forward, the env step writing straight into the rollout buffer, and -- with
+        a time limit -- V(terminal observation) of the rows the step truncated (a masked forward: tiles without a
+        truncated row are skipped on the device); then V(last obs) and ``r6_gae``."""
+        env, cfg, T = self.env, self.cfg, self.cfg.n_steps
+        base = self._step_base
+        self.buf_obs[0].copy_(self._obs)
+        for t in range(T):
+            self._rollout_step += 1
+            self.fused(self.buf_obs[t], step_index=self._rollout_step, step_base=base,
+                       out=(self._act_clip, self.buf_act[t], self.buf_val[t], self.buf_logp[t]))
+            env.step_into(self._act_clip, obs=self.buf_obs[t + 1] if t + 1 < T else self._obs, reward=self.buf_rew[t],
+                          done=self.buf_done[t], flags=self.buf_flags[t] if self._time_limit else None)
+            if self._time_limit:
+                bo = self._boot_out
+                self.fused(env.final_obs, deterministic=True, step_index=0, out=(bo[0], bo[1], self.buf_boot[t], bo[3]),
+                           row_flags=self.buf_flags[t], flag_mask=FLAG_TRUNCATED)
+        bo = self._boot_out
+        self.fused(self._obs, deterministic=True, step_index=0, out=(bo[0], bo[1], self._last_val, bo[3]))
+        self._gae(self._last_val)
+
+    def _gae(self, last_values):
+        """GAE(lambda) into ``self.adv`` / ``self.ret``: one launch of ``r6_gae`` on the GPU (time-limit bootstrap folded
+        in when ``buf_flags`` / ``buf_boot`` exist), the torch loop ``compute_gae`` otherwise."""
+        cfg, (T, n) = self.cfg, self.buf_rew.shape
+        lib = getattr(self.fused, "lib", None) or getattr(self.fused_update, "lib", None)
+        if lib is None or self.device.type != "cuda":
+            adv, ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done.to(torch.float32), last_values, cfg.gamma, cfg.gae_lambda)
+            self.adv.copy_(adv)      # persistent buffers: the graphed update step reads these addresses
+            self.ret.copy_(ret)
+            return
+        from . import _lib
+
+        tl = self.fused is not None and self._time_limit and self._in_kernel_bootstrap
+        with torch.cuda.device(self.device):
+            rc = lib.r6_gae(self.buf_rew.data_ptr(), self.buf_val.data_ptr(), self.buf_done.data_ptr(), last_values.data_ptr(), T, n,
+                            cfg.gamma, cfg.gae_lambda, self.buf_flags.data_ptr() if tl else None, FLAG_TRUNCATED,
+                            self.buf_boot.data_ptr() if tl else None, self.adv.data_ptr(), self.ret.data_ptr(),
+                            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        _lib.check(rc, "r6_gae", lib)
+
     @torch.no_grad()
     def collect_rollouts(self):
         env, cfg = self.env, self.cfg
         if self._obs is None:
             self._obs = env.reset().clone()
         T = cfg.n_steps
+        self._in_kernel_bootstrap = False
+        if self.fused is not None and self._direct:
+            self._in_kernel_bootstrap = True
+            if cfg.graph_rollout and self._rollouts >= 1:        # the first rollout runs eagerly (one-time set-up in the launch paths)
+                if self._rollout_graph is None:
+                    # recording runs the Python side once (the host step counters advance by T, nothing executes);
+                    # every replay then continues the RNG streams through the device-side base instead
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._rollout_launches()
+                        self._step_base.add_(T)
+                    self._rollout_graph = g
+                    self._step_base.zero_()
+                self._rollout_graph.replay()
+            else:
+                self._rollout_launches()
+            self._rollouts += 1
+            self.num_timesteps += cfg.n_steps * self.global_envs
+            return
         self.buf_obs[0].copy_(self._obs)
         for t in range(T):
             if self.fused is not None:
@@ -440,10 +517,7 @@ class PPO:
             self.buf_done[t].copy_(done)
             (self.buf_obs[t + 1] if t + 1 < T else self._obs).copy_(obs)
         self.num_timesteps += cfg.n_steps * self.global_envs     # the whole job, ragged shards included
-        last_values = self.policy.value(self._obs)
-        adv, ret = compute_gae(self.buf_rew, self.buf_val, self.buf_done, last_values, cfg.gamma, cfg.gae_lambda)
-        self.adv.copy_(adv)      # persistent buffers: the graphed update step reads these addresses
-        self.ret.copy_(ret)
+        self._gae(self.policy.value(self._obs).contiguous())
 
     def _sync_grads(self):
         if self.world == 1:
