@@ -274,8 +274,9 @@ int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std
  * (R6PolicyNet.shared = 1, hidden1 = 128, hidden2 = 64, obs_dim 13 | 14).
  *   obs (rows, obs_dim), action (rows, 3), old_logp / adv / ret [rows]: the rollout buffer; `index` [n] (int64, or NULL for
  *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
- *   grad: WRITTEN (not accumulated), torch.nn.Linear layouts like the weights.  stats [8] written: pg_loss, v_loss, entropy,
- *   clip_frac, approx_kl, n.  scratch: r6_ppo_scratch_floats() floats of device memory owned by the caller. */
+ *   grad: WRITTEN (not accumulated), torch.nn.Linear layouts like the weights.  stats [16]: [0..7] written: pg_loss, v_loss,
+ *   entropy, clip_frac, approx_kl, n; [8..15] += the same six (running sums over launches: the caller zeroes them when a new sum
+ *   starts and reads means once per update).  scratch: r6_ppo_scratch_floats() floats of device memory owned by the caller. */
 typedef struct R6PolicyGrad {
     float *w1, *b1;             /* trunk layer 1: [128][obs_dim], [128] */
     float *w2, *b2;             /* trunk layer 2: [64][128], [64] */
@@ -285,9 +286,11 @@ typedef struct R6PolicyGrad {
 } R6PolicyGrad;
 size_t r6_policy_grad_size(void);   /* sizeof(R6PolicyGrad) */
 /* out2 = [mean, 1 / (std + 1e-8)] (unbiased std) of adv[index[0..n)] (index NULL: adv[0..n)): SB3's per-minibatch
- * advantage normalisation, the `adv_norm` input of the two loss entry points, without a gathered copy.  scratch: 256 doubles
- * of device memory owned by the caller. */
-int r6_minibatch_adv_norm(const float *adv, const int64_t *index, int64_t n, float *out2, double *scratch, void *stream);
+ * advantage normalisation, the `adv_norm` input of the two loss entry points, without a gathered copy.  n_batches > 1: the
+ * consecutive minibatches index[b n .. (b + 1) n) of an epoch's permutation in one call, out2[b][2].  scratch: 256 doubles
+ * per minibatch, device memory owned by the caller. */
+int r6_minibatch_adv_norm(const float *adv, const int64_t *index, int64_t n, int64_t n_batches, float *out2, double *scratch,
+                          void *stream);
 size_t r6_ppo_scratch_floats(void);
 int r6_ppo_minibatch_grad(const R6PolicyNet *net, const float *obs, const float *action, const float *old_logp,
                           const float *adv, const float *ret, const int64_t *index, int64_t n, const float *adv_norm,

@@ -589,13 +589,19 @@ __global__ __launch_bounds__(256) void ppo_grad_reduce_kernel(const float* __res
         if (k < 3) gr.pi_b3[k] = v;
         else if (k == 3) gr.vf_b3[0] = v;
         else if (k < 7) gr.log_std[k - 4] = v - ent_coef;   // entropy = sum_i (0.5 + 0.5 ln 2pi + log_std_i): d(ent_coef * -ent) = -ent_coef
-        else if (k == 7) stats[0] = v * inv_n;              // pg loss
-        else if (k == 8) stats[1] = v * inv_n;              // value loss
-        else if (k == 9) stats[3] = v * inv_n;              // clip fraction
+        // stats[8 + j] is the running sum of stats[j] over the launches since the caller last zeroed it (one writer per
+        // entry and launches are stream-ordered: no atomics) -- a training loop reads its means once per update, no add kernel
+        else if (k == 7) { stats[0] = v * inv_n; stats[8] += v * inv_n; }       // pg loss
+        else if (k == 8) { stats[1] = v * inv_n; stats[9] += v * inv_n; }       // value loss
+        else if (k == 9) { stats[3] = v * inv_n; stats[11] += v * inv_n; }      // clip fraction
         else if (k == 10) {
+            const float ent = 3.0f * 1.4189385332046727f + log_std[0] + log_std[1] + log_std[2];
             stats[4] = v * inv_n;                           // approx kl
-            stats[2] = 3.0f * 1.4189385332046727f + log_std[0] + log_std[1] + log_std[2];   // entropy
+            stats[12] += v * inv_n;
+            stats[2] = ent;                                 // entropy
+            stats[10] += ent;
             stats[5] = n_samples;
+            stats[13] += n_samples;
         }
     }
 }
@@ -641,12 +647,15 @@ int launch(const R6PolicyNet& net, const Args& a, const R6PolicyGrad& gr, float*
 // sums of x and x^2 in float64 (128 workgroups: a single one spends 158 us on the dependent index -> value loads of 65 536
 // samples), then one wave folds the partial sums.
 constexpr int kNormBlocks = 128;
+// (blockIdx.y = minibatch b of a batched call: rows index[b * n .. (b + 1) * n), partial sums part[b][..], result out[b][2])
 __global__ __launch_bounds__(256) void adv_norm_partial_kernel(const float* __restrict__ adv, const int64_t* __restrict__ index, const int64_t n,
                                                                 double* __restrict__ part) {
     __shared__ double r1[4], r2[4];
     double s1 = 0.0, s2 = 0.0;
+    const int64_t first = (int64_t)blockIdx.y * n;
+    part += (int64_t)blockIdx.y * 2 * gridDim.x;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double x = (double)adv[index ? index[i] : i];
+        const double x = (double)adv[index ? index[first + i] : first + i];
         s1 += x;
         s2 += x * x;
     }
@@ -666,6 +675,8 @@ __global__ __launch_bounds__(256) void adv_norm_partial_kernel(const float* __re
     }
 }
 __global__ __launch_bounds__(64) void adv_norm_final_kernel(const double* __restrict__ part, const int n_part, const int64_t n, float* __restrict__ out) {
+    part += (int64_t)blockIdx.x * 2 * n_part;
+    out += 2 * blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < n_part; k += 64) {
         s1 += part[2 * k];
@@ -772,16 +783,17 @@ extern "C" int r6_adam_clip_step(float* param, const float* grad, float* exp_avg
     return 0;
 }
 
-extern "C" int r6_minibatch_adv_norm(const float* adv, const int64_t* index, int64_t n, float* out2, double* scratch, void* stream) {
-    if (!adv || !out2 || !scratch || n <= 0) {
-        r6_internal_set_error("r6_minibatch_adv_norm: adv, out, scratch (256 doubles) and n > 0 are required");
+extern "C" int r6_minibatch_adv_norm(const float* adv, const int64_t* index, int64_t n, int64_t n_batches, float* out2, double* scratch,
+                                     void* stream) {
+    if (!adv || !out2 || !scratch || n <= 0 || n_batches <= 0 || n_batches > 65535) {
+        r6_internal_set_error("r6_minibatch_adv_norm: adv, out, scratch (256 doubles per minibatch), n > 0 and 1 <= n_batches <= 65535 are required");
         return R6_E_BADARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     int blocks = (int)((n + 255) / 256);
     if (blocks > r6u::kNormBlocks) blocks = r6u::kNormBlocks;
-    hipLaunchKernelGGL(r6u::adv_norm_partial_kernel, dim3(blocks), dim3(256), 0, s, adv, index, n, scratch);
-    hipLaunchKernelGGL(r6u::adv_norm_final_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, n, out2);
+    hipLaunchKernelGGL(r6u::adv_norm_partial_kernel, dim3(blocks, (unsigned)n_batches), dim3(256), 0, s, adv, index, n, scratch);
+    hipLaunchKernelGGL(r6u::adv_norm_final_kernel, dim3((unsigned)n_batches), dim3(64), 0, s, scratch, blocks, n, out2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         r6_internal_set_error(hipGetErrorString(e));

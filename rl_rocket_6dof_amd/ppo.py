@@ -153,7 +153,7 @@ class FusedMinibatchGrad:
             self.grads.append(self.flat_g[off:off + k].view_as(t))
             off += k
         self.log_std_offset = off - sizes[-1]
-        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(16, dtype=torch.float32, device=self.device)   # [0..7] last launch, [8..15] running sums
         self.norm = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._norm_scratch = torch.zeros(256, dtype=torch.float64, device=self.device)
         self.scratch = torch.empty(int(self.lib.r6_ppo_scratch_floats()), dtype=torch.float32, device=self.device)
@@ -176,21 +176,33 @@ class FusedMinibatchGrad:
         from . import _lib
         _lib.check(rc, "r6_adam_clip_step", self.lib)
 
-    def adv_norm(self, adv, index):
-        """[mean, 1 / (std + 1e-8)] of ``adv[index]`` (SB3's per-minibatch advantage normalisation) in one small launch."""
+    def adv_norm(self, adv, index, n_batches: int = 1):
+        """[mean, 1 / (std + 1e-8)] of ``adv[index]`` (SB3's per-minibatch advantage normalisation) in two small launches.
+        ``n_batches`` > 1: ``index`` holds that many consecutive minibatches of equal size (an epoch's permutation);
+        returns a (n_batches, 2) tensor, one pair per minibatch."""
         C = self._C
-        n = int(index.numel()) if index is not None else int(adv.numel())
+        total = int(index.numel()) if index is not None else int(adv.numel())
+        if n_batches < 1 or total % n_batches:
+            raise ValueError("the index does not split into n_batches equal minibatches")
+        if n_batches == 1:
+            out, scratch = self.norm, self._norm_scratch
+        else:
+            if getattr(self, "_norms", None) is None or self._norms.shape[0] != n_batches:
+                self._norms = torch.zeros((n_batches, 2), dtype=torch.float32, device=self.device)
+                self._norms_scratch = torch.zeros(256 * n_batches, dtype=torch.float64, device=self.device)
+            out, scratch = self._norms, self._norms_scratch
         with torch.cuda.device(self.device):
-            rc = self.lib.r6_minibatch_adv_norm(C.c_void_p(adv.data_ptr()), None if index is None else C.c_void_p(index.data_ptr()), n,
-                                                C.c_void_p(self.norm.data_ptr()), C.c_void_p(self._norm_scratch.data_ptr()),
+            rc = self.lib.r6_minibatch_adv_norm(C.c_void_p(adv.data_ptr()), None if index is None else C.c_void_p(index.data_ptr()),
+                                                total // n_batches, n_batches, C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()),
                                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         from . import _lib
         _lib.check(rc, "r6_minibatch_adv_norm", self.lib)
-        return self.norm
+        return out
 
     def __call__(self, obs, action, old_logp, adv, ret, index, adv_norm, clip, vf_coef, ent_coef):
         """Writes the gradients of the minibatch ``index`` (int64 rows of the rollout tensors; None = all rows) into the
-        parameters' ``.grad`` and returns the stats tensor [pg_loss, v_loss, entropy, clip_frac, approx_kl, n, -, -]."""
+        parameters' ``.grad`` and returns the stats tensor [pg_loss, v_loss, entropy, clip_frac, approx_kl, n, -, -] of this
+        launch, followed by the running sums of the same eight over all launches since ``stats[8:]`` was last zeroed."""
         C, net = self._C, self._net
         net.obs_dim, net.hidden1, net.hidden2, net.shared = self.obs_dim, self.ARCH[0], self.ARCH[1], 1
         for name, t in zip(("pi_w1", "pi_b1", "pi_w2", "pi_b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.params):
@@ -535,14 +547,17 @@ class PPO:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
-    def _minibatch_step(self, mb, flat, acc):
-        """One SB3 ``PPO.train`` minibatch: loss, backward, (all-reduce), grad-norm clip, Adam; stats into ``acc``."""
+    def _minibatch_step(self, mb, flat, acc, norm=None):
+        """One SB3 ``PPO.train`` minibatch: loss, backward, (all-reduce), grad-norm clip, Adam; stats into ``acc`` (the fused
+        kernel keeps its own running sums: ``FusedMinibatchGrad.stats[8:]``).  ``norm``: this minibatch's advantage
+        normalisation when the caller computed it for a whole epoch at once."""
         cfg = self.cfg
         obs, act, old_logp, adv, ret = flat
         if self.fused_update is not None:
             # forward + loss + backward of the whole minibatch in one launch; rows picked by index inside the kernel
-            norm = self.fused_update.adv_norm(adv, mb) if cfg.normalize_advantage and mb.numel() > 1 else None
-            st = self.fused_update(obs, act, old_logp, adv, ret, mb, norm, cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
+            if norm is None and cfg.normalize_advantage and mb.numel() > 1:
+                norm = self.fused_update.adv_norm(adv, mb)
+            self.fused_update(obs, act, old_logp, adv, ret, mb, norm, cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
             if self.world > 1:     # one bucket, already flat: each rank's mean gradient enters with its share of the samples
                 g = self.fused_update.flat_g
                 g.mul_(self._grad_weight)
@@ -555,8 +570,6 @@ class PPO:
             # clip_grad_norm_ + Adam (SB3: eps 1e-5) + the log-std floor: one launch on the flat arrays
             self.fused_update.adam_step(self.opt.param_groups[0]["lr"], cfg.max_grad_norm, cfg.log_std_min,
                                         betas=self.opt.param_groups[0]["betas"], eps=self.opt.param_groups[0]["eps"])
-            with torch.no_grad():
-                acc += st[:5]
             return
         a = adv[mb]
         fused = cfg.fused_loss and self.device.type == "cuda"
@@ -603,10 +616,16 @@ class PPO:
             return self._graph
         self._mb_idx = torch.zeros(chunk * bs, dtype=torch.int64, device=self.device)
         self._acc = torch.zeros(5, dtype=torch.float32, device=self.device)
+        batched_norm = self.fused_update is not None and self.cfg.normalize_advantage and bs > 1
+        if batched_norm:
+            self.fused_update.adv_norm(flat[3], self._mb_idx, chunk)     # allocates its buffers outside the capture
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
+            norms = None
+            if batched_norm:
+                norms = self.fused_update.adv_norm(flat[3], self._mb_idx, chunk).view(chunk, 2)   # the whole chunk's minibatches at once
             for c in range(chunk):
-                self._minibatch_step(self._mb_idx[c * bs:(c + 1) * bs], flat, self._acc)
+                self._minibatch_step(self._mb_idx[c * bs:(c + 1) * bs], flat, self._acc, None if norms is None else norms[c])
         self._graph_key = key
         return self._graph
 
@@ -627,6 +646,8 @@ class PPO:
         keys = ("pg_loss", "v_loss", "entropy", "clip_frac", "approx_kl")
         use_graph = cfg.graph_update and self.device.type == "cuda" and self.world == 1 and bs <= (1 << 17)
         acc = torch.zeros(len(keys), dtype=torch.float32, device=self.device)   # summed on the device: no per-batch sync
+        if self.fused_update is not None:
+            self.fused_update.stats[8:].zero_()      # the gradient kernel keeps the running sums itself
         n_batches = 0
         steps = self._steps_per_epoch                              # the same count on every rank (agreed in __init__)
         chunk = self._graph_chunk(steps) if use_graph else 1
@@ -650,6 +671,8 @@ class PPO:
         if use_graph and self._graph is not None:
             acc += self._acc
             self._acc.zero_()
+        if self.fused_update is not None:
+            acc += self.fused_update.stats[8:13]
         out = (acc / max(n_batches, 1)).tolist()
         return dict(zip(keys, out))
 

@@ -237,3 +237,35 @@ def test_fused_adam_clip_step_matches_torch():
             assert err <= 2e-7 + 2e-6 * float(b.abs().max()) * 0 + 3e-7, (it, na, err)
     assert int(fused.adam_step_count) == 4
     assert float(pol.log_std.min()) >= -2.5
+
+
+def test_batched_advantage_norm_and_running_stats():
+    """r6_minibatch_adv_norm over an epoch's consecutive minibatches == one call per minibatch == torch; the gradient
+    kernel's running sums stats[8:] add up its per-launch stats."""
+    import torch
+
+    from rl_rocket_6dof_amd.ppo import ActorCritic, FusedMinibatchGrad
+
+    torch.manual_seed(2)
+    rows, bs, nb, od = 50000, 4096, 7, 13
+    pol = ActorCritic(od, 3, (128, 64), shared_trunk=True).cuda()
+    fused = FusedMinibatchGrad(pol)
+    adv = torch.randn(rows, device="cuda") * 3 + 1
+    perm = torch.randperm(rows, device="cuda")[: nb * bs].contiguous()
+    batched = fused.adv_norm(adv, perm, nb).clone()
+    for b in range(nb):
+        mb = perm[b * bs:(b + 1) * bs]
+        one = fused.adv_norm(adv, mb).clone()
+        assert torch.equal(one, batched[b])
+        ref = torch.stack([adv[mb].mean(), 1.0 / (adv[mb].std() + 1e-8)])
+        assert float((one - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    with pytest.raises(ValueError):
+        fused.adv_norm(adv, perm[:-1], nb)
+    obs, act = torch.randn(rows, od, device="cuda"), torch.randn(rows, 3, device="cuda")
+    old, ret = torch.randn(rows, device="cuda") - 3, torch.randn(rows, device="cuda")
+    fused.stats.zero_()
+    tot = torch.zeros(6, device="cuda")
+    for b in range(3):
+        st = fused(obs, act, old, adv, ret, perm[b * bs:(b + 1) * bs], batched[b], 0.2, 0.5, 0.0)
+        tot += st[:6]
+    assert float((fused.stats[8:14] - tot).abs().max()) <= 1e-5 * float(tot.abs().max())
