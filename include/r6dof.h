@@ -306,6 +306,12 @@ int r6_adam_clip_step(float *param, const float *grad, float *exp_avg, float *ex
                       float lr, const float *lr_dev, float beta1, float beta2, float eps, int64_t *step_dev,
                       int64_t clamp_off, int64_t clamp_n, float clamp_min, void *stream);
 
+/* out[0..n) = a pseudo-random permutation of 0..n-1 keyed by (seed, counter + *counter_base): the minibatch order of an SB3
+ * epoch (`RolloutBuffer.get`: np.random.permutation, stable_baselines3/common/buffers.py) as ONE elementwise launch -- a
+ * keyed bijection with cycle walking, no sort.  counter_base (device, [1], or NULL) as in R6Buffers.step_base: a recorded
+ * launch draws a new permutation at every graph replay once the caller advances it. */
+int r6_permutation(int64_t *out, int64_t n, uint64_t seed, uint64_t counter, const uint64_t *counter_base, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ _LIBS = {}
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad",
            "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad", "r6_minibatch_adv_norm", "r6_adam_clip_step",
-           "r6_gae")
+           "r6_gae", "r6_permutation")
 
 
 class R6Error(RuntimeError):
@@ -68,6 +68,8 @@ def load(path: str | None = None):
     lib.r6_adam_clip_step.restype = C.c_int
     lib.r6_gae.argtypes = [vp, vp, vp, vp, i64, i64, f32, f32, vp, C.c_int, vp, vp, vp, vp]
     lib.r6_gae.restype = C.c_int
+    lib.r6_permutation.argtypes = [vp, i64, u64, u64, vp, vp]
+    lib.r6_permutation.restype = C.c_int
     if lib.r6_policy_grad_size() != C.sizeof(R6PolicyGrad):
         raise ImportError("R6PolicyGrad layout mismatch between params.py and libr6dof.so: rebuild")
     for name in ("r6_step", "r6_step_k", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):

@@ -695,6 +695,40 @@ __global__ __launch_bounds__(64) void adv_norm_final_kernel(const double* __rest
     }
 }
 
+// A pseudo-random permutation of 0..n-1 without a sort (r6_permutation): out[i] = P(i), P a keyed bijection of [0, 2^bits)
+// (bits = ceil(log2 n)) restricted to [0, n) by cycle walking -- values that land in [n, 2^bits) are pushed through P again,
+// fewer than two applications per element on average.  P alternates steps that are each invertible modulo 2^bits: xor with a
+// round key, multiplication by an odd round constant (carries information upwards), xor with the value shifted right (brings
+// it back down), in the manner of Kensler's `permute` (Correlated Multi-Jittered Sampling, 2013).  torch.randperm sorts
+// random keys instead: 0.22 ms for 2^20 elements on this GPU, a seventh of a PPO epoch of sixteen fused minibatch steps.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {   // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void permutation_kernel(int64_t* __restrict__ out, const int64_t n, const uint64_t seed, const uint64_t counter,
+                                                           const uint64_t* __restrict__ counter_base) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = counter + (counter_base ? *counter_base : (uint64_t)0);
+    const int bits = (n > 2) ? 64 - __builtin_clzll((uint64_t)(n - 1)) : 1;
+    const uint64_t mask = (bits >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << bits) - 1);
+    const int s1 = (bits + 1) / 2, s2 = (bits > 3) ? bits / 3 : 1;
+    uint64_t key[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) key[r] = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(r + 1) + mix64(c + (uint64_t)r * 0xD1342543DE82EF95ull));
+    uint64_t x = (uint64_t)i;
+    do {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            x ^= key[r] & mask;
+            x = (x * ((key[r] >> 17) | 1)) & mask;
+            x ^= x >> ((r & 1) ? s2 : s1);
+        }
+    } while (x >= (uint64_t)n);
+    out[i] = (int64_t)x;
+}
+
 // GAE(lambda) of a rollout, one lane per env walking its T steps backwards (r6_gae; SB3 RolloutBuffer.compute_returns_and_advantage).
 // The recurrence is serial in t but the loads are not: the unrolled loop keeps eight steps of (reward, value, done) in flight.
 __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
@@ -794,6 +828,22 @@ extern "C" int r6_minibatch_adv_norm(const float* adv, const int64_t* index, int
     if (blocks > r6u::kNormBlocks) blocks = r6u::kNormBlocks;
     hipLaunchKernelGGL(r6u::adv_norm_partial_kernel, dim3(blocks, (unsigned)n_batches), dim3(256), 0, s, adv, index, n, scratch);
     hipLaunchKernelGGL(r6u::adv_norm_final_kernel, dim3((unsigned)n_batches), dim3(64), 0, s, scratch, blocks, n, out2);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        r6_internal_set_error(hipGetErrorString(e));
+        return -(int)e;
+    }
+    return 0;
+}
+
+extern "C" int r6_permutation(int64_t* out, int64_t n, uint64_t seed, uint64_t counter, const uint64_t* counter_base, void* stream) {
+    if (!out || n < 0) {
+        r6_internal_set_error("r6_permutation: out and n >= 0 are required");
+        return R6_E_BADARG;
+    }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(r6u::permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, seed,
+                       counter, counter_base);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         r6_internal_set_error(hipGetErrorString(e));

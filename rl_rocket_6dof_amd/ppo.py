@@ -63,6 +63,8 @@ class PPOConfig:
     graph_update: bool = True        # replay the minibatch step as a HIP graph when it is launch-bound (<= 2^17 samples)
     fused_policy: bool = True        # rollouts through the fused HIP forward (policy.FusedActorCritic) when the
                                      # net shape is supported and the env is on a GPU; torch modules otherwise
+    fast_permutation: bool = True    # minibatch order from r6_permutation (a keyed bijection, one elementwise launch, part of
+                                     # the epoch's graph) instead of torch.randperm (a sort: 0.22 ms per 2^20 rows); GPU only
     graph_rollout: bool = True       # with the fused forward: a whole rollout (n_steps x (policy, env step, time-limit
                                      # bootstrap) + GAE) is recorded once into a HIP graph and replayed -- three launches
                                      # per step and no host work; the RNG counters advance through a device-side base
@@ -354,8 +356,12 @@ class PPO:
         lr = torch.tensor(float(cfg.learning_rate), device=self.device) if capt else cfg.learning_rate
         self.opt = torch.optim.Adam(self.policy.parameters(), lr=lr, eps=1e-5, capturable=capt)
         self._graph, self._graph_key, self._eager_steps = None, None, 0
+        self._perm_count, self._perm_base = 0, None
         rank = dist.get_rank() if self.world > 1 else 0
         self.gen = torch.Generator(device=self.device).manual_seed(cfg.seed + 1000003 * rank)
+        self._perm_seed = (cfg.seed + 1000003 * rank) * 2654435761 + 97
+        if self.device.type == "cuda":
+            self._perm_base = torch.zeros((), dtype=torch.int64, device=self.device)
         n, T = env.num_envs, cfg.n_steps
         if getattr(env, "max_episode_steps", 0) and (getattr(env, "flags", None) is None or getattr(env, "final_obs", None) is None):
             # without the truncation flag and the terminal observation the time-limit bootstrap gamma * V(s_T) cannot
@@ -604,26 +610,44 @@ class PPO:
                 acc += torch.stack([pg, v_loss, -ent, ((ratio - 1).abs() > cfg.clip_range).float().mean(),
                                     ((ratio - 1) - (logp - old_logp[mb])).mean()])
 
-    def _graphed_steps(self, flat, bs, chunk):
+    def _permute(self, out: torch.Tensor, base: Optional[torch.Tensor] = None):
+        """``out[:] = `` a fresh pseudo-random permutation of 0..len(out)-1 (``r6_permutation``; host counter + device base key
+        it, as for the rollout's RNG streams)."""
+        from . import _lib
+
+        lib = self.fused_update.lib
+        self._perm_count += 1
+        with torch.cuda.device(self.device):
+            rc = lib.r6_permutation(out.data_ptr(), out.numel(), self._perm_seed, self._perm_count, None if base is None else base.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        _lib.check(rc, "r6_permutation", lib)
+        return out
+
+    def _graphed_steps(self, flat, bs, chunk, total=0):
         """``chunk`` consecutive minibatch steps captured once into a HIP graph (static index / stats buffers) and
         replayed: at minibatches of <= 2^17 samples the ~250 kernels of a torch step are launch-bound in eager mode
         (2.1 ms per step at 65 536 samples against ~0.4 ms of GPU work), and with the fused kernels (4 launches,
         ~0.09 ms per step) even one index copy + one graph launch per STEP is a fifth of the time -- so a whole
         epoch's steps (up to 32) share one replay and one copy of the permutation.  Single-process only (no
         collective inside)."""
-        key = (bs, chunk) + tuple(t.data_ptr() for t in flat)
+        key = (bs, chunk, total) + tuple(t.data_ptr() for t in flat)
         if self._graph is not None and self._graph_key == key:
             return self._graph
-        self._mb_idx = torch.zeros(chunk * bs, dtype=torch.int64, device=self.device)
+        # total > 0: the graph also draws the epoch's permutation of the `total` rollout rows into the index buffer
+        self._mb_idx = torch.zeros(max(chunk * bs, total), dtype=torch.int64, device=self.device)
         self._acc = torch.zeros(5, dtype=torch.float32, device=self.device)
         batched_norm = self.fused_update is not None and self.cfg.normalize_advantage and bs > 1
         if batched_norm:
-            self.fused_update.adv_norm(flat[3], self._mb_idx, chunk)     # allocates its buffers outside the capture
+            self.fused_update.adv_norm(flat[3], self._mb_idx[:chunk * bs], chunk)     # allocates its buffers outside the capture
         self._graph = torch.cuda.CUDAGraph()
+        idx = self._mb_idx[:chunk * bs]
         with torch.cuda.graph(self._graph):
+            if total:
+                self._permute(self._mb_idx[:total], self._perm_base)
+                self._perm_base.add_(1)
             norms = None
             if batched_norm:
-                norms = self.fused_update.adv_norm(flat[3], self._mb_idx, chunk).view(chunk, 2)   # the whole chunk's minibatches at once
+                norms = self.fused_update.adv_norm(flat[3], idx, chunk).view(chunk, 2)   # the whole chunk's minibatches at once
             for c in range(chunk):
                 self._minibatch_step(self._mb_idx[c * bs:(c + 1) * bs], flat, self._acc, None if norms is None else norms[c])
         self._graph_key = key
@@ -651,15 +675,22 @@ class PPO:
         n_batches = 0
         steps = self._steps_per_epoch                              # the same count on every rank (agreed in __init__)
         chunk = self._graph_chunk(steps) if use_graph else 1
+        fast = cfg.fast_permutation and self.fused_update is not None
+        if fast and (getattr(self, "_perm_buf", None) is None or self._perm_buf.numel() != total):
+            self._perm_buf = torch.zeros(total, dtype=torch.int64, device=self.device)
         for _ in range(cfg.n_epochs):
-            perm = torch.randperm(total, device=self.device, generator=self.gen)
+            if fast and use_graph and chunk == steps and self._eager_steps >= 3:
+                self._graphed_steps(flat, bs, chunk, total).replay()      # permutation + every minibatch step of the epoch: one replay
+                n_batches += steps
+                continue
+            perm = self._permute(self._perm_buf) if fast else torch.randperm(total, device=self.device, generator=self.gen)
             s = 0
             while s < steps:
                 # the first steps run eagerly (allocator / Adam state warm-up), and so does the rest of that epoch when
                 # it is shorter than a chunk
                 if use_graph and self._eager_steps >= 3 and s + chunk <= steps:
                     g = self._graphed_steps(flat, bs, chunk)
-                    self._mb_idx.copy_(perm[s * bs:(s + chunk) * bs])
+                    self._mb_idx[:chunk * bs].copy_(perm[s * bs:(s + chunk) * bs])
                     g.replay()
                     s += chunk
                     n_batches += chunk

@@ -168,3 +168,58 @@ def test_launch_only_rollout_matches_the_per_step_torch_loop():
         assert torch.equal(res[0][i], res[1][i]), i
     for i in (4, 5):
         assert float((res[0][i] - res[1][i]).abs().max()) <= 2e-5 * float(res[1][i].abs().max()), i
+
+
+def _permutation_replica(n, seed, c):
+    """numpy restatement of r6_permutation (keyed bijection of [0, 2^bits) + cycle walking): integer work, compared bit for bit."""
+    import numpy as np
+
+    M = (1 << 64) - 1
+
+    def mix64(z):
+        z &= M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    bits = (n - 1).bit_length() if n > 2 else 1
+    mask = (1 << bits) - 1
+    s1, s2 = (bits + 1) // 2, (bits // 3 if bits > 3 else 1)
+    key = [mix64(seed + 0x9E3779B97F4A7C15 * (r + 1) + mix64(c + r * 0xD1342543DE82EF95)) for r in range(6)]
+    x = np.arange(n, dtype=np.uint64)
+    todo = np.ones(n, bool)
+    while todo.any():
+        y = x[todo]
+        for r in range(6):
+            y ^= np.uint64(key[r] & mask)
+            y = (y * np.uint64((key[r] >> 17) | 1)) & np.uint64(mask)
+            y ^= y >> np.uint64(s2 if r & 1 else s1)
+        x[todo] = y
+        todo = x >= n
+    return x.astype(np.int64)
+
+
+def test_r6_permutation_is_a_keyed_permutation():
+    import numpy as np
+    import torch
+
+    from rl_rocket_6dof_amd import _lib
+
+    lib = _lib.load()
+    for n in (1, 2, 3, 7, 1000, 12345, 1 << 16, (1 << 20) - 3, 1 << 20):
+        out = torch.full((n,), -1, dtype=torch.int64, device="cuda")
+        _lib.check(lib.r6_permutation(out.data_ptr(), n, 42, 5, None, None), "r6_permutation", lib)
+        p = out.cpu().numpy()
+        assert np.array_equal(np.sort(p), np.arange(n)), n
+        assert np.array_equal(p, _permutation_replica(n, 42, 5)), n
+    n = 1 << 20
+    base = torch.tensor(3, dtype=torch.int64, device="cuda")
+    a, b, c = (torch.empty(n, dtype=torch.int64, device="cuda") for _ in range(3))
+    lib.r6_permutation(a.data_ptr(), n, 9, 8, None, None)
+    lib.r6_permutation(b.data_ptr(), n, 9, 5, base.data_ptr(), None)
+    lib.r6_permutation(c.data_ptr(), n, 9, 6, base.data_ptr(), None)
+    assert torch.equal(a, b) and int((a == c).sum()) < 32            # counter + base keys it; the next counter: unrelated order
+    p = a.cpu().numpy().astype(np.float64)
+    assert abs(np.corrcoef(np.arange(n), p)[0, 1]) < 5e-3 and abs(np.corrcoef(p[:-1], p[1:])[0, 1]) < 5e-3
+    mb = p.reshape(16, -1).mean(1) / n                                # sixteen minibatches: each a fair sample of the rows
+    assert np.abs(mb - 0.5).max() < 5e-3
