@@ -270,19 +270,22 @@ int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std
  * SB3 1.6 `PPO.train` per minibatch (stable_baselines3/ppo/ppo.py, behind main_6DOF.py:107-139): evaluate_actions on the
  * minibatch rows, the clipped-surrogate / value / entropy loss of r6_ppo_loss_grad, and loss.backward() through the
  * actor-critic -- forward, loss and backward fused, on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32).  Supported
- * net: the reference's topology, ONE shared tanh trunk obs -> 128 -> 64 with a 3-output action head and a value head
- * (R6PolicyNet.shared = 1, hidden1 = 128, hidden2 = 64, obs_dim 13 | 14).
+ * nets (obs_dim 13 | 14): the reference's topology, ONE shared tanh trunk obs -> 128 -> 64 with a 3-output action head and a
+ * value head (R6PolicyNet.shared = 1, hidden (128, 64)), and SB3's default, two separate tanh MLPs obs -> 64 -> 64
+ * (shared = 0, hidden (64, 64); BASELINE configs[4] "SB3 PPO MLP(64,64)").
  *   obs (rows, obs_dim), action (rows, 3), old_logp / adv / ret [rows]: the rollout buffer; `index` [n] (int64, or NULL for
  *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
  *   grad: WRITTEN (not accumulated), torch.nn.Linear layouts like the weights.  stats [16]: [0..7] written: pg_loss, v_loss,
  *   entropy, clip_frac, approx_kl, n; [8..15] += the same six (running sums over launches: the caller zeroes them when a new sum
  *   starts and reads means once per update).  scratch: r6_ppo_scratch_floats() floats of device memory owned by the caller. */
 typedef struct R6PolicyGrad {
-    float *w1, *b1;             /* trunk layer 1: [128][obs_dim], [128] */
-    float *w2, *b2;             /* trunk layer 2: [64][128], [64] */
+    float *w1, *b1;             /* trunk (or policy MLP) layer 1: [hidden1][obs_dim], [hidden1] */
+    float *w2, *b2;             /* trunk (or policy MLP) layer 2: [hidden2][hidden1], [hidden2] */
     float *pi_w3, *pi_b3;       /* action head: [3][64], [3] */
     float *vf_w3, *vf_b3;       /* value head: [1][64], [1] */
     float *log_std;             /* [3] */
+    float *vf_w1, *vf_b1;       /* value MLP of a net with separate MLPs (R6PolicyNet.shared = 0); NULL for a shared trunk */
+    float *vf_w2, *vf_b2;
 } R6PolicyGrad;
 size_t r6_policy_grad_size(void);   /* sizeof(R6PolicyGrad) */
 /* out2 = [mean, 1 / (std + 1e-8)] (unbiased std) of adv[index[0..n)] (index NULL: adv[0..n)): SB3's per-minibatch

@@ -43,9 +43,10 @@ namespace r6u {
 constexpr int kBlock = 256, kWaves = 4;
 constexpr int kPitch = 36;                 // floats per row of the transposed tiles: 32 samples (even ones first, then the odd ones) + 4,
                                            // 16-byte aligned rows whose 16-float halves are read conflict-free as 4 x ds_read_b128
-constexpr int kP1 = 12, kP2 = 20;          // floats per lane of the weight images (8 / 16 used): conflict-free ds_read_b128 pitches
-constexpr int kNumBlocks = 12;             // 32x32 accumulator blocks per wave: dW2 (8), dW1 (4)
-constexpr int kFeat = 5 * 64;              // per layer-2 feature f: dW3^T[f][0..3] and db2[f], summed on the VALU with lane = feature
+constexpr int kP2 = 20;                    // floats per lane of the layer-2 weight images (16 used): a conflict-free ds_read_b128 pitch
+constexpr int kNumBlocks = 12;             // 32x32 accumulator blocks per wave: dW2 (8) + dW1 (4), shared trunk [128, 64] or two MLPs (64, 64)
+constexpr int kFeatNet = 5 * 64;           // per net and layer-2 feature f: dW3^T[f][0..3] and db2[f], summed on the VALU with lane = feature
+constexpr int kFeat = 2 * kFeatNet;        // room for two nets (a shared trunk uses the first half)
 constexpr int kScalars = 16;               // db3[4], dlog_std[3], pg, v, clip_frac, kl (+ pad)
 constexpr int kOffFeat = kNumBlocks * 1024, kOffScal = kOffFeat + kFeat;
 constexpr int kPartial = kOffScal + kScalars;   // one workgroup's partial set: [blocks][feat][scalars]
@@ -85,13 +86,18 @@ __device__ __forceinline__ void wave_sync() {
 //   w2t  [H1/32][H2/32][64][kP2]     A of the delta chain: W2[32c + row(r, l>>5)][ib*32 + (l&31)]
 //   b2   [H2/32][2][16]              accumulator init of layer 2: b2[mb*32 + row(r,h)]
 //   w3   [2][H2/32][16][4]           heads: {pi_w3[0..2][32c + row(r,h)], vf_w3[32c + row(r,h)]}
-template <int H1, int H2>
+// NETS = 1: one trunk feeding both heads (R6PolicyNet.shared); NETS = 2: net 0 = the policy MLP, net 1 = the value MLP, every
+// image holds net 0's chains first.  w3 rows are 4 wide for both nets (columns 0..2 action head, 3 value head), with zeros in
+// the columns a net does not feed, so heads, delta2 and the dW3 sums are the same code for every net.
+template <int NETS, int H1, int H2>
 struct Image {
-    static constexpr int oW1 = 0, kW1 = (H1 / 32) * 64 * kP1;
-    static constexpr int oW2 = oW1 + kW1, kW2 = (H2 / 32) * (H1 / 32) * 64 * kP2;
+    static constexpr int kP1 = (NETS == 2) ? 8 : 12;   // floats per lane of the layer-1 image (8 used); 12 is the conflict-free pitch, two
+                                                       // nets trade it (2 reads per chain, 2-way conflicts) for 4 KB of LDS
+    static constexpr int oW1 = 0, kW1 = NETS * (H1 / 32) * 64 * kP1;
+    static constexpr int oW2 = oW1 + kW1, kW2 = NETS * (H2 / 32) * (H1 / 32) * 64 * kP2;
     static constexpr int oW2T = oW2 + kW2;
-    static constexpr int oB2 = oW2T + kW2, kB2 = (H2 / 32) * 2 * 16;
-    static constexpr int oW3 = oB2 + kB2, kW3 = 2 * (H2 / 32) * 16 * 4;
+    static constexpr int oB2 = oW2T + kW2, kB2 = NETS * (H2 / 32) * 2 * 16;
+    static constexpr int oW3 = oB2 + kB2, kW3 = NETS * 2 * (H2 / 32) * 16 * 4;
     static constexpr int kImage = oW3 + kW3;
     // per-wave staging (transposed tiles): a2 / delta2 [H2][kPitch], one 32-row block [32][kPitch], x [16][kPitch], g [4][kPitch]
     static constexpr int sT2 = 0, sBlk = H2 * kPitch, sX = sBlk + 32 * kPitch, sG = sX + 16 * kPitch;
@@ -132,11 +138,12 @@ struct Args {
 #define R6U_MARK(k) do { } while (0)
 #endif
 
-template <int H1, int H2, int OD>
+template <int NETS, int H1, int H2, int OD>
 __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet net, const Args a, float* __restrict__ partial) {
-    using Im = Image<H1, H2>;
-    constexpr int B1 = H1 / 32, B2 = H2 / 32;
-    static_assert(B2 == 2 && B1 * B2 + B1 == kNumBlocks && 5 * H2 == kFeat, "accumulator block count is sized for H2 = 64, H1 = 128");
+    using Im = Image<NETS, H1, H2>;
+    constexpr int B1 = H1 / 32, B2 = H2 / 32, kP1 = Im::kP1;
+    constexpr int kNetBlocks = B2 * B1 + B1;   // accumulator blocks of one net: dW2 [mb][ib], then dW1 [ib]
+    static_assert(B2 == 2 && NETS * kNetBlocks == kNumBlocks && 5 * H2 == kFeatNet, "sized for a shared trunk [128, 64] or two MLPs (64, 64)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,32 +155,42 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #endif
     // ---- stage the weight images -------------------------------------------------------------------------------------
 #pragma unroll 8
-    for (int e = tid; e < (H1 / 32) * 64 * 8; e += kBlock) {
-        const int s = e & 7, l = (e >> 3) & 63, blk = e >> 9;
+    for (int e = tid; e < NETS * B1 * 64 * 8; e += kBlock) {
+        const int s = e & 7, l = (e >> 3) & 63, chain = e >> 9;   // chain = net * B1 + blk
+        const int ni = chain / B1, blk = chain % B1;
         const int k = 2 * s + (l >> 5), m = blk * 32 + (l & 31);
-        lds[Im::oW1 + (blk * 64 + l) * kP1 + s] = (k < OD) ? net.pi_w1[m * OD + k] : ((k == OD) ? net.pi_b1[m] : 0.0f);
+        const float* w = ni ? net.vf_w1 : net.pi_w1;
+        const float* b = ni ? net.vf_b1 : net.pi_b1;
+        lds[Im::oW1 + (chain * 64 + l) * kP1 + s] = (k < OD) ? w[m * OD + k] : ((k == OD) ? b[m] : 0.0f);
     }
 #pragma unroll 8   // independent gathers from L2: eight in flight per thread instead of one round trip per element
-    for (int e = tid; e < B2 * B1 * 64 * 16; e += kBlock) {
+    for (int e = tid; e < NETS * B2 * B1 * 64 * 16; e += kBlock) {
         const int r = e & 15, l = (e >> 4) & 63, rest = e >> 10;
-        {   // w2: rest = mb * B1 + b
-            const int b = rest % B1, mb = rest / B1;
-            lds[Im::oW2 + (rest * 64 + l) * kP2 + r] = net.pi_w2[(mb * 32 + (l & 31)) * H1 + 32 * b + rowmap(r, l >> 5)];
+        const int ni = rest / (B2 * B1), loc = rest % (B2 * B1);
+        const float* w = ni ? net.vf_w2 : net.pi_w2;
+        {   // w2: chain (net * B2 + mb) * B1 + b
+            const int b = loc % B1, mb = loc / B1;
+            lds[Im::oW2 + (rest * 64 + l) * kP2 + r] = w[(mb * 32 + (l & 31)) * H1 + 32 * b + rowmap(r, l >> 5)];
         }
-        {   // w2t: rest = ib * B2 + c
-            const int c = rest % B2, ib = rest / B2;
-            lds[Im::oW2T + (rest * 64 + l) * kP2 + r] = net.pi_w2[(32 * c + rowmap(r, l >> 5)) * H1 + ib * 32 + (l & 31)];
+        {   // w2t: chain (net * B1 + ib) * B2 + c
+            const int c = loc % B2, ib = loc / B2;
+            lds[Im::oW2T + (rest * 64 + l) * kP2 + r] = w[(32 * c + rowmap(r, l >> 5)) * H1 + ib * 32 + (l & 31)];
         }
     }
-    for (int e = tid; e < Im::kB2; e += kBlock) {
-        const int r = e & 15, hh = (e >> 4) & 1, mb = e >> 5;
-        lds[Im::oB2 + e] = net.pi_b2[mb * 32 + rowmap(r, hh)];
+    for (int e = tid; e < Im::kB2; e += kBlock) {   // ((net * B2 + mb) * 2 + h) * 16 + r
+        const int r = e & 15, hh = (e >> 4) & 1, rest = e >> 5;
+        const int ni = rest / B2, mb = rest % B2;
+        lds[Im::oB2 + e] = (ni ? net.vf_b2 : net.pi_b2)[mb * 32 + rowmap(r, hh)];
     }
-    for (int e = tid; e < Im::kW3; e += kBlock) {
+    for (int e = tid; e < Im::kW3; e += kBlock) {   // (((net * 2 + h) * B2 + mb) * 16 + r) * 4 + o
         const int o = e & 3, r = (e >> 2) & 15, rest = e >> 6;
-        const int c = rest % B2, hh = rest / B2;
+        const int c = rest % B2, hh = (rest / B2) & 1, ni = rest / (2 * B2);
         const int k = 32 * c + rowmap(r, hh);
-        lds[Im::oW3 + e] = (o < 3) ? net.pi_w3[o * H2 + k] : net.vf_w3[k];
+        float v;
+        if (NETS == 1) v = (o < 3) ? net.pi_w3[o * H2 + k] : net.vf_w3[k];
+        else if (ni == 0) v = (o < 3) ? net.pi_w3[o * H2 + k] : 0.0f;
+        else v = (o == 3) ? net.vf_w3[k] : 0.0f;
+        lds[Im::oW3 + e] = v;
     }
     __syncthreads();
 
@@ -210,25 +227,28 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     // The 11 running sums of a lane (db3[4], dlog_std[3], pg, v, clip_frac, kl) live in LDS, in the padding of the w2 image
     // (pitch kP2 = 20, 16 used): lane l of wave w owns float 16 + w of its row in chain k.  In registers they were the
     // first thing the allocator parked in scratch (11 reload-add-spill round trips per tile).
-    static_assert(kP2 - 16 >= kWaves && 2 * B2 * B1 >= 11 && Im::oW2T == Im::oW2 + Im::kW2, "stat slots fit into the padding of the w2 and w2t images (contiguous)");
+    static_assert(kP2 - 16 >= kWaves && 2 * NETS * B2 * B1 >= 11 && Im::oW2T == Im::oW2 + Im::kW2, "stat slots fit into the padding of the w2 and w2t images (contiguous)");
     int o_stat = Im::oW2 + lane * kP2 + 16 + wave;
 #pragma unroll
     for (int k = 0; k < 11; ++k) lds[o_stat + k * 64 * kP2] = 0.0f;
 
     // ---- accumulators of the launch -----------------------------------------------------------------------------------
-    f32x16 acc_w2[B2][B1], acc_w1[B1];
-    float f_w3[4] = {0.0f, 0.0f, 0.0f, 0.0f}, f_b2 = 0.0f;   // lane = layer-2 feature: dW3^T[lane][0..3], db2[lane]
+    f32x16 acc[kNumBlocks];                                  // net-major: dW2 [mb][ib] (iW2), then dW1 [ib] (iW1)
+    auto iW2 = [](int ni, int mb, int ib) __attribute__((always_inline)) { return ni * kNetBlocks + mb * B1 + ib; };
+    auto iW1 = [](int ni, int ib) __attribute__((always_inline)) { return ni * kNetBlocks + B2 * B1 + ib; };
+    float f_w3[NETS][4], f_b2[NETS];                         // lane = layer-2 feature: dW3^T[lane][0..3], db2[lane]
+#pragma unroll
+    for (int ni = 0; ni < NETS; ++ni) {
+        f_b2[ni] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) f_w3[ni][o] = 0.0f;
+    }
     int q_fr = (stage0 + lane * kPitch) >> 2;                // row `lane` of the transposed a2 / delta2 tile
     int q_g = (stage0 + Im::sG) >> 2;                        // g's four rows (the same address in every lane: LDS broadcast)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int k = 0; k < kNumBlocks; ++k) {
 #pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
-#pragma unroll
-            for (int ib = 0; ib < B1; ++ib) acc_w2[mb][ib][r] = 0.0f;
-        }
-#pragma unroll
-        for (int ib = 0; ib < B1; ++ib) acc_w1[ib][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
     }
 
     const int64_t n_tiles = (a.n + 31) >> 5;
@@ -279,57 +299,63 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #ifdef R6U_STAMPS
         uint64_t mark_ = wall_clock64();
 #endif
-        // ---- forward -----------------------------------------------------------------------------------------------------
-        f32x16 a1[B1], a2[B2];
+        // ---- forward: one net after the other (the two MLPs share nothing but x) ------------------------------------------
+        f32x16 a1[NETS][B1], a2[NETS][B2];
 #pragma unroll
-        for (int blk = 0; blk < B1; ++blk) {
-            f32x16 z;
+        for (int ni = 0; ni < NETS; ++ni) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-            float wa[8];
-            ldv<8>(&lds[Im::oW1 + (blk * 64 + lane) * kP1], wa);
+            for (int blk = 0; blk < B1; ++blk) {
+                f32x16 z;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) z = mfma(wa[s], xk[s], z);
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                float wa[8];
+                ldv<8>(&lds[Im::oW1 + ((ni * B1 + blk) * 64 + lane) * kP1], wa);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[blk][r] = tanh_fast(z[r]);
-            R6U_CHAIN_FENCE();   // one chain at a time: operand loads hoisted from later chains would spill, and with
-                                                 // one wave per SIMD a scratch access is an exposed memory round trip
-        }
-        R6U_MARK(0);   // F1
-        {   // chains c = mb * B1 + b; the next chain's 16 weights are fetched while this chain runs on the matrix core
-            float wa[2][16];
-            ldv<16>(&lds[Im::oW2 + lane * kP2], wa[0]);
-            f32x16 z;
+                for (int s = 0; s < 8; ++s) z = mfma(wa[s], xk[s], z);
 #pragma unroll
-            for (int c = 0; c < B2 * B1; ++c) {
-                const int mb = c / B1, b = c % B1;
-                if (b == 0) {
-                    float zi[16];
-                    ldv<16>(b2_base + mb * 32, zi);
+                for (int r = 0; r < 16; ++r) a1[ni][blk][r] = tanh_fast(z[r]);
+                R6U_CHAIN_FENCE();   // one chain at a time: operand loads hoisted from later chains would spill, and with
+                                     // one wave per SIMD a scratch access is an exposed memory round trip
+            }
+            {   // chains c = mb * B1 + b; the next chain's 16 weights are fetched while this chain runs on the matrix core
+                constexpr int kC = B2 * B1;
+                float wa[2][16];
+                ldv<16>(&lds[Im::oW2 + (ni * kC * 64 + lane) * kP2], wa[0]);
+                f32x16 z;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = zi[r];
+                for (int c = 0; c < kC; ++c) {
+                    const int mb = c / B1, b = c % B1;
+                    if (b == 0) {
+                        float zi[16];
+                        ldv<16>(b2_base + (ni * B2 + mb) * 32, zi);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = zi[r];
+                    }
+                    if (c + 1 < kC) ldv<16>(&lds[Im::oW2 + ((ni * kC + c + 1) * 64 + lane) * kP2], wa[(c + 1) & 1]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z = mfma(wa[c & 1][r], a1[ni][b][r], z);
+                    if (b == B1 - 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) a2[ni][mb][r] = tanh_fast(z[r]);
+                    }
+                    R6U_CHAIN_FENCE();
                 }
-                if (c + 1 < B2 * B1) ldv<16>(&lds[Im::oW2 + ((c + 1) * 64 + lane) * kP2], wa[(c + 1) & 1]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z = mfma(wa[c & 1][r], a1[b][r], z);
-                if (b == B1 - 1) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) a2[mb][r] = tanh_fast(z[r]);
-                }
-                R6U_CHAIN_FENCE();
             }
         }
-        R6U_MARK(1);   // F2
+        R6U_MARK(1);   // forward
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
+        for (int ni = 0; ni < NETS; ++ni) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + (mb * 16 + r) * 4);
-                part[0] = fmaf(w3[0], a2[mb][r], part[0]);
-                part[1] = fmaf(w3[1], a2[mb][r], part[1]);
-                part[2] = fmaf(w3[2], a2[mb][r], part[2]);
-                part[3] = fmaf(w3[3], a2[mb][r], part[3]);
+            for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + (mb * 16 + r) * 4);
+                    part[0] = fmaf(w3[0], a2[ni][mb][r], part[0]);
+                    part[1] = fmaf(w3[1], a2[ni][mb][r], part[1]);
+                    part[2] = fmaf(w3[2], a2[ni][mb][r], part[2]);
+                    part[3] = fmaf(w3[3], a2[ni][mb][r], part[3]);
+                }
             }
         }
         const float m0 = part[0] + __shfl_xor(part[0], 32) + b3_0;
@@ -366,118 +392,121 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         }
 
         R6U_MARK(2);   // heads + loss
-        // ---- dW3^T[f][o] += sum_s a2[f][s] g[o][s]: a2 and g transposed through LDS, samples on K ---------------------------
-#pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = a2[mb][r];
-        }
         if (h == 0) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) tw_base[Im::sG + o * kPitch] = g[o];
         }
-        wave_sync();
-        // On the VALU, lane = feature (H2 = 64 rows of the tile, one per lane): 128 FMAs -- as an MFMA product with 4 useful
-        // columns of 32 this took 32 matrix instructions (2048+ cycles) and two accumulator blocks.
+        // ---- backward, one net after the other --------------------------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
+        for (int ni = 0; ni < NETS; ++ni) {
+            if (ni > 0) wave_sync();   // the previous net's readers of the tile buffers are done
+            // dW3^T[f][o] += sum_s a2[f][s] g[o][s]: a2 transposed through LDS; on the VALU, lane = feature (H2 = 64 rows of
+            // the tile, one per lane): 128 FMAs -- as an MFMA product with 4 useful columns of 32 this took 32 matrix
+            // instructions (2048+ cycles) and two accumulator blocks
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + o_g + o * kPitch + 4 * q);
-                f_w3[o] = fmaf(av[0], gv[0], fmaf(av[1], gv[1], fmaf(av[2], gv[2], fmaf(av[3], gv[3], f_w3[o]))));
+            for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = a2[ni][mb][r];
             }
-        }
-
-        R6U_MARK(3);   // G3 (+ staging of a2, g, x)
-        // ---- delta2 = (W3^T g) (1 - a2^2): this lane half's 16 rows per block ------------------------------------------------
-        f32x16 d2[B2];
-#pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + (mb * 16 + r) * 4);
-                const float up = fmaf(w3[0], g[0], fmaf(w3[1], g[1], fmaf(w3[2], g[2], w3[3] * g[3])));
-                d2[mb][r] = up * fmaf(-a2[mb][r], a2[mb][r], 1.0f);
-            }
-        }
-        wave_sync();   // dW3's reads of the a2 tile are done: delta2 takes its place
-#pragma unroll
-        for (int mb = 0; mb < B2; ++mb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = d2[mb][r];
-        }
-        wave_sync();
-        // db2[f] += sum_s delta2[f][s]: lane = feature again, a row sum
-        {
-            float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            wave_sync();
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
-                rs[0] += dv[0];
-                rs[1] += dv[1];
-                rs[2] += dv[2];
-                rs[3] += dv[3];
+                const f32x4 av = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + o_g + o * kPitch + 4 * q);
+                    f_w3[ni][o] = fmaf(av[0], gv[0], fmaf(av[1], gv[1], fmaf(av[2], gv[2], fmaf(av[3], gv[3], f_w3[ni][o]))));
+                }
             }
-            f_b2 += (rs[0] + rs[1]) + (rs[2] + rs[3]);
-        }
-
-        R6U_MARK(4);   // delta2 + db2
-        // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) ----------------------
+            R6U_MARK(3);   // dW3 sums (+ staging of a2)
+            // ---- delta2 = (W3^T g) (1 - a2^2): this lane half's 16 rows per block ---------------------------------------------
+            f32x16 d2[B2];
 #pragma unroll
-        for (int ib = 0; ib < B1; ++ib) {
-            wave_sync();   // the block buffer's previous readers are done
+            for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = a1[ib][r];
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + (mb * 16 + r) * 4);
+                    const float up = fmaf(w3[0], g[0], fmaf(w3[1], g[1], fmaf(w3[2], g[2], w3[3] * g[3])));
+                    d2[mb][r] = up * fmaf(-a2[ni][mb][r], a2[ni][mb][r], 1.0f);
+                }
+            }
+            wave_sync();   // the dW3 sums' reads of the a2 tile are done: delta2 takes its place
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = d2[mb][r];
+            }
             wave_sync();
-            // dW2[f2][i] += sum_s delta2[f2][s] a1[i][s]
-            // Each chain's operands are fetched while the chain before it runs (static_assert: B2 == 2).
-            float op[2][16], bx[16];
+            // db2[f] += sum_s delta2[f][s]: lane = feature again, a row sum
             {
-                float ba[16];
-                ldv<16>(tr_base + Im::sBlk, ba);
-                ldv<16>(tr_base + Im::sT2, op[0]);
-                ldv<16>(tr_base + Im::sT2 + 32 * kPitch, op[1]);
+                float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc_w2[0][ib] = mfma(op[0][s], ba[s], acc_w2[0][ib]);
-                R6U_CHAIN_FENCE();
-                ldv<16>(&lds[Im::oW2T + ((ib * B2 + 0) * 64 + lane) * kP2], op[0]);
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc_w2[1][ib] = mfma(op[1][s], ba[s], acc_w2[1][ib]);
-                R6U_CHAIN_FENCE();
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
+                    rs[0] += dv[0];
+                    rs[1] += dv[1];
+                    rs[2] += dv[2];
+                    rs[3] += dv[3];
+                }
+                f_b2[ni] += (rs[0] + rs[1]) + (rs[2] + rs[3]);
             }
-            R6U_MARK(5);   // G2
-            // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
-            f32x16 d1;
+            R6U_MARK(4);   // delta2 + db2
+            // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) -------------------
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
-            ldv<16>(&lds[Im::oW2T + ((ib * B2 + 1) * 64 + lane) * kP2], op[1]);
+            for (int ib = 0; ib < B1; ++ib) {
+                wave_sync();   // the block buffer's previous readers are done
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1 = mfma(op[0][r], d2[0][r], d1);
-            R6U_CHAIN_FENCE();
-            ldv<16>(tr_base + Im::sX - col * kPitch + (col & 15) * kPitch, bx);   // x's row (col & 15): B of dW1 below
+                for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = a1[ni][ib][r];
+                wave_sync();
+                // dW2[f2][i] += sum_s delta2[f2][s] a1[i][s]
+                // Each chain's operands are fetched while the chain before it runs (static_assert: B2 == 2).
+                float op[2][16], bx[16];
+                {
+                    float ba[16];
+                    ldv<16>(tr_base + Im::sBlk, ba);
+                    ldv<16>(tr_base + Im::sT2, op[0]);
+                    ldv<16>(tr_base + Im::sT2 + 32 * kPitch, op[1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1 = mfma(op[1][r], d2[1][r], d1);
-            R6U_CHAIN_FENCE();
+                    for (int s = 0; s < 16; ++s) acc[iW2(ni, 0, ib)] = mfma(op[0][s], ba[s], acc[iW2(ni, 0, ib)]);
+                    R6U_CHAIN_FENCE();
+                    ldv<16>(&lds[Im::oW2T + (((ni * B1 + ib) * B2 + 0) * 64 + lane) * kP2], op[0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ib][r], a1[ib][r], 1.0f);
-            R6U_MARK(6);   // B2
-            wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
+                    for (int s = 0; s < 16; ++s) acc[iW2(ni, 1, ib)] = mfma(op[1][s], ba[s], acc[iW2(ni, 1, ib)]);
+                    R6U_CHAIN_FENCE();
+                }
+                R6U_MARK(5);   // G2
+                // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
+                f32x16 d1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
-            wave_sync();
-            // dW1[i][k] += sum_s delta1[i][s] x[k][s]   (k == OD: db1, through x's column of ones)
-            {
-                ldv<16>(tr_base + Im::sBlk, op[0]);
+                for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+                ldv<16>(&lds[Im::oW2T + (((ni * B1 + ib) * B2 + 1) * 64 + lane) * kP2], op[1]);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc_w1[ib] = mfma(op[0][s], (col < 16) ? bx[s] : 0.0f, acc_w1[ib]);
+                for (int r = 0; r < 16; ++r) d1 = mfma(op[0][r], d2[0][r], d1);
                 R6U_CHAIN_FENCE();
+                ldv<16>(tr_base + Im::sX - col * kPitch + (col & 15) * kPitch, bx);   // x's row (col & 15): B of dW1 below
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1 = mfma(op[1][r], d2[1][r], d1);
+                R6U_CHAIN_FENCE();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ni][ib][r], a1[ni][ib][r], 1.0f);
+                R6U_MARK(6);   // B2
+                wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
+                wave_sync();
+                // dW1[i][k] += sum_s delta1[i][s] x[k][s]   (k == OD: db1, through x's column of ones)
+                {
+                    ldv<16>(tr_base + Im::sBlk, op[0]);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) acc[iW1(ni, ib)] = mfma(op[0][s], (col < 16) ? bx[s] : 0.0f, acc[iW1(ni, ib)]);
+                    R6U_CHAIN_FENCE();
+                }
+                R6U_MARK(7);   // G1
             }
-            R6U_MARK(7);   // G1
         }
     }
 
-    // ---- workgroup reduction: scalars, then the 16 accumulator blocks one after the other through one LDS block ---------------
+    // ---- workgroup reduction: scalars, per-feature sums, then the accumulator blocks four at a time through the staging areas ----
 #ifdef R6U_STAMPS
     const uint64_t ts2 = wall_clock64();
 #endif
@@ -498,13 +527,17 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     if (tid < kScalars) reds[tid] = (tid < 11) ? (reds[tid] + reds[kScalars + tid]) + (reds[2 * kScalars + tid] + reds[3 * kScalars + tid]) : 0.0f;
     __syncthreads();
     if (tid < kScalars) out[kOffScal + tid] = reds[tid];
-    {   // per-feature sums: [kWaves][kFeat] behind the scalars, then one thread per entry adds the four waves
+    {   // per-feature sums: [kWaves][net][5][64] behind the scalars, then one thread per entry adds the four waves
+        constexpr int kF = NETS * kFeatNet;
         float* fr = lds + kWaves * kScalars;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) fr[wave * kFeat + o * 64 + lane] = f_w3[o];
-        fr[wave * kFeat + 4 * 64 + lane] = f_b2;
+        for (int ni = 0; ni < NETS; ++ni) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) fr[wave * kF + ni * kFeatNet + o * 64 + lane] = f_w3[ni][o];
+            fr[wave * kF + ni * kFeatNet + 4 * 64 + lane] = f_b2[ni];
+        }
         __syncthreads();
-        for (int e = tid; e < kFeat; e += kBlock) out[kOffFeat + e] = (fr[e] + fr[kFeat + e]) + (fr[2 * kFeat + e] + fr[3 * kFeat + e]);
+        for (int e = tid; e < kF; e += kBlock) out[kOffFeat + e] = (fr[e] + fr[kF + e]) + (fr[2 * kF + e] + fr[3 * kF + e]);
     }
     // Blocks: every wave writes its accumulator block to its own LDS slab in canonical [m][n] order (the staging areas are
     // free now: four blocks fit into each), then the workgroup adds the four slabs in a fixed order -- no atomics (a float
@@ -525,16 +558,14 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     };
     static_assert(Im::kStage >= 4 * 1024, "a wave's staging area holds four accumulator blocks");
     __syncthreads();
-    // dW2: blocks 0..7, four per round
+    // the 12 blocks in their net-major order, four per round
+    static_assert(kNumBlocks % 4 == 0, "whole rounds");
 #pragma unroll
-    for (int mb = 0; mb < B2; ++mb) {
+    for (int round = 0; round < kNumBlocks / 4; ++round) {
 #pragma unroll
-        for (int ib = 0; ib < B1; ++ib) put(acc_w2[mb][ib], ib);
-        drain(mb * B1, B1);
+        for (int k = 0; k < 4; ++k) put(acc[round * 4 + k], k);
+        drain(round * 4, 4);
     }
-#pragma unroll
-    for (int ib = 0; ib < B1; ++ib) put(acc_w1[ib], ib);
-    drain(B2 * B1, B1);
 #ifdef R6U_STAMPS
     if (tid == 0) {   // 100 MHz ticks: staging, tile loop of wave 0, reduction
         out[kOffScal + 12] = (float)(ts1 - ts0);
@@ -545,7 +576,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 }
 
 // Sums the partial sets of all workgroups and scatters them into torch's parameter layouts ([out][in] row-major).
-template <int H1, int H2, int OD>
+template <int NETS, int H1, int H2, int OD>
 __global__ __launch_bounds__(1024) void ppo_grad_reduce_kernel(const float* __restrict__ partial, const int n_sets, const R6PolicyGrad gr,
                                                               const float* __restrict__ log_std, const float ent_coef, const float inv_n,
                                                               const float n_samples, float* __restrict__ stats) {
@@ -574,20 +605,32 @@ __global__ __launch_bounds__(1024) void ppo_grad_reduce_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < kW; k += 4) v += (red[k][threadIdx.x] + red[k + 1][threadIdx.x]) + (red[k + 2][threadIdx.x] + red[k + 3][threadIdx.x]);
     if (e < kNumBlocks * 1024) {
+        constexpr int kNetBlocks = B2 * B1 + B1;
         const int blk = e >> 10, m = (e >> 5) & 31, nn = e & 31;
-        if (blk < B2 * B1) {                       // dW2[mb*32 + m][ib*32 + n]
-            const int mb = blk / B1, ib = blk % B1;
-            gr.w2[(mb * 32 + m) * H1 + ib * 32 + nn] = v;
+        const int ni = blk / kNetBlocks, loc = blk % kNetBlocks;   // net 1 (two MLPs): the value net's trunk
+        if (loc < B2 * B1) {                       // dW2[mb*32 + m][ib*32 + n]
+            const int mb = loc / B1, ib = loc % B1;
+            (ni ? gr.vf_w2 : gr.w2)[(mb * 32 + m) * H1 + ib * 32 + nn] = v;
         } else {                                   // dW1[ib*32 + m][k = n], k == OD: db1
-            const int ib = blk - B2 * B1;
-            if (nn < OD) gr.w1[(ib * 32 + m) * OD + nn] = v;
-            else if (nn == OD) gr.b1[ib * 32 + m] = v;
+            const int ib = loc - B2 * B1;
+            if (nn < OD) (ni ? gr.vf_w1 : gr.w1)[(ib * 32 + m) * OD + nn] = v;
+            else if (nn == OD) (ni ? gr.vf_b1 : gr.b1)[ib * 32 + m] = v;
         }
-    } else if (e < kOffScal) {                     // per-feature sums: dW3^T[f][o] (o < 3: action head, o == 3: value head), db2[f]
-        const int o = (e - kOffFeat) >> 6, f = (e - kOffFeat) & 63;
-        if (o < 3) gr.pi_w3[o * H2 + f] = v;
-        else if (o == 3) gr.vf_w3[f] = v;
-        else gr.b2[f] = v;
+    } else if (e < kOffScal) {                     // per-feature sums [net][5][64]: dW3^T[f][o] (o < 3: action head, o == 3: value head), db2[f]
+        const int idx = e - kOffFeat;
+        const int ni = idx / kFeatNet, o = (idx % kFeatNet) >> 6, f = idx & 63;
+        if (ni >= NETS) return;
+        if (NETS == 1) {
+            if (o < 3) gr.pi_w3[o * H2 + f] = v;
+            else if (o == 3) gr.vf_w3[f] = v;
+            else gr.b2[f] = v;
+        } else if (ni == 0) {
+            if (o < 3) gr.pi_w3[o * H2 + f] = v;
+            else if (o == 4) gr.b2[f] = v;
+        } else {
+            if (o == 3) gr.vf_w3[f] = v;
+            else if (o == 4) gr.vf_b2[f] = v;
+        }
     } else {
         const int k = e - kOffScal;
         if (k < 3) gr.pi_b3[k] = v;
@@ -610,11 +653,11 @@ __global__ __launch_bounds__(1024) void ppo_grad_reduce_kernel(const float* __re
     }
 }
 
-template <int H1, int H2, int OD>
+template <int NETS, int H1, int H2, int OD>
 int launch(const R6PolicyNet& net, const Args& a, const R6PolicyGrad& gr, float* stats, float* scratch, size_t scratch_floats,
            hipStream_t s) {
-    auto kernel = ppo_grad_kernel<H1, H2, OD>;
-    constexpr size_t lds_bytes = sizeof(float) * Image<H1, H2>::kTotal;
+    auto kernel = ppo_grad_kernel<NETS, H1, H2, OD>;
+    constexpr size_t lds_bytes = sizeof(float) * Image<NETS, H1, H2>::kTotal;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     static std::atomic<bool> configured[16];
@@ -636,7 +679,7 @@ int launch(const R6PolicyNet& net, const Args& a, const R6PolicyGrad& gr, float*
         return R6_E_BADARG;
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, s, net, a, scratch);
-    hipLaunchKernelGGL((ppo_grad_reduce_kernel<H1, H2, OD>), dim3((kPartial + 63) / 64), dim3(1024), 0, s, scratch, (int)blocks, gr,
+    hipLaunchKernelGGL((ppo_grad_reduce_kernel<NETS, H1, H2, OD>), dim3((kPartial + 63) / 64), dim3(1024), 0, s, scratch, (int)blocks, gr,
                        net.log_std, a.ent_coef, 1.0f / (float)a.n, (float)a.n, stats);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -891,17 +934,27 @@ extern "C" int r6_ppo_minibatch_grad(const R6PolicyNet* net, const float* obs, c
     }
     const R6PolicyNet& p = *net;
     const R6PolicyGrad& g = *grad;
-    if (!p.shared || p.hidden1 != 128 || p.hidden2 != 64 || (p.obs_dim != 13 && p.obs_dim != 14)) {
-        r6_internal_set_error("r6_ppo_minibatch_grad: supported net: one shared trunk (R6PolicyNet.shared = 1), hidden (128, 64), obs_dim 13|14");
+    const bool trunk = p.shared && p.hidden1 == 128 && p.hidden2 == 64;      // the reference's net_arch=[128, 64]
+    const bool two = !p.shared && p.hidden1 == 64 && p.hidden2 == 64;        // SB3's default: separate (64, 64) MLPs
+    if (!(trunk || two) || (p.obs_dim != 13 && p.obs_dim != 14)) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: supported nets: one shared trunk (128, 64) or two separate MLPs (64, 64); obs_dim 13|14");
         return R6_E_BADARG;
     }
     if (!p.pi_w1 || !p.pi_b1 || !p.pi_w2 || !p.pi_b2 || !p.pi_w3 || !p.pi_b3 || !p.vf_w3 || !p.vf_b3 || !p.log_std ||
         !g.w1 || !g.b1 || !g.w2 || !g.b2 || !g.pi_w3 || !g.pi_b3 || !g.vf_w3 || !g.vf_b3 || !g.log_std) {
-        r6_internal_set_error("r6_ppo_minibatch_grad: trunk / head pointers of R6PolicyNet and every R6PolicyGrad pointer are required");
+        r6_internal_set_error("r6_ppo_minibatch_grad: trunk / head pointers of R6PolicyNet and of R6PolicyGrad are required");
+        return R6_E_BADARG;
+    }
+    if (two && (!p.vf_w1 || !p.vf_b1 || !p.vf_w2 || !p.vf_b2 || !g.vf_w1 || !g.vf_b1 || !g.vf_w2 || !g.vf_b2)) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: separate MLPs need vf_w1, vf_b1, vf_w2, vf_b2 in R6PolicyNet and R6PolicyGrad");
         return R6_E_BADARG;
     }
     r6u::Args a{obs, action, old_logp, adv, ret, index, adv_norm, n, clip_range, vf_coef, ent_coef};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (p.obs_dim == 13) return r6u::launch<128, 64, 13>(p, a, g, stats, scratch, scratch_floats, s);
-    return r6u::launch<128, 64, 14>(p, a, g, stats, scratch, scratch_floats, s);
+    if (trunk) {
+        if (p.obs_dim == 13) return r6u::launch<1, 128, 64, 13>(p, a, g, stats, scratch, scratch_floats, s);
+        return r6u::launch<1, 128, 64, 14>(p, a, g, stats, scratch, scratch_floats, s);
+    }
+    if (p.obs_dim == 13) return r6u::launch<2, 64, 64, 13>(p, a, g, stats, scratch, scratch_floats, s);
+    return r6u::launch<2, 64, 64, 14>(p, a, g, stats, scratch, scratch_floats, s);
 }

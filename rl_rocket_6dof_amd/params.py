@@ -252,5 +252,6 @@ def make_params(env_config: dict, *, integrator: str = "rk4", n_substeps: Option
 
 
 class R6PolicyGrad(C.Structure):
-    """include/r6dof.h ``R6PolicyGrad``: device pointers to the gradient buffers of the shared-trunk net."""
-    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std")]
+    """include/r6dof.h ``R6PolicyGrad``: device pointers to the gradient buffers (vf_w1..vf_b2: separate value MLP only)."""
+    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std",
+                                          "vf_w1", "vf_b1", "vf_w2", "vf_b2")]

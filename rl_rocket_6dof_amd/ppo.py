@@ -109,17 +109,24 @@ class FusedMinibatchGrad:
     ``loss.backward()`` -- as ONE HIP launch (``r6_ppo_minibatch_grad``, csrc/r6_ppo_update.hip): parameter gradients come out
     on the matrix cores in exact fp32, no activation goes to HBM and the minibatch rows are picked by index (no gathered
     copies).  Supported: the reference's topology, one shared tanh trunk obs -> 128 -> 64 with both heads on it
-    (``ActorCritic(net_arch=(128, 64), shared_trunk=True)``).  The gradient tensors are persistent and become the
-    parameters' ``.grad``, so clipping, the all-reduce and Adam run unchanged behind it."""
+    (``ActorCritic(net_arch=(128, 64), shared_trunk=True)``), and SB3's default, two separate tanh MLPs obs -> 64 -> 64
+    (``ActorCritic(net_arch=(64, 64), shared_trunk=False)``; BASELINE configs[4]).  The gradient tensors are persistent and
+    become the parameters' ``.grad``, so clipping, the all-reduce and Adam run unchanged behind it."""
 
-    ARCH = (128, 64)
+    ARCH = (128, 64)             # the shared trunk
+    ARCH_SEPARATE = (64, 64)     # two MLPs
 
     @staticmethod
     def supports(policy) -> bool:
-        lin = [m for m in policy.pi if isinstance(m, nn.Linear)]
-        return bool(getattr(policy, "shared_trunk", False)) and len(lin) == 3 and \
-            (lin[0].out_features, lin[1].out_features) == FusedMinibatchGrad.ARCH and lin[0].in_features in (13, 14) and \
-            lin[2].out_features == 3 and policy.log_std.is_cuda
+        pi = [m for m in policy.pi if isinstance(m, nn.Linear)]
+        vf = [m for m in policy.vf if isinstance(m, nn.Linear)]
+        if len(pi) != 3 or len(vf) != 3 or pi[0].in_features not in (13, 14) or pi[2].out_features != 3 or vf[2].out_features != 1 \
+                or not policy.log_std.is_cuda:
+            return False
+        arch = (pi[0].out_features, pi[1].out_features)
+        if bool(getattr(policy, "shared_trunk", False)):
+            return arch == FusedMinibatchGrad.ARCH and pi[0] is vf[0] and pi[1] is vf[1]
+        return arch == FusedMinibatchGrad.ARCH_SEPARATE and (vf[0].out_features, vf[1].out_features) == arch and pi[0] is not vf[0]
 
     def __init__(self, policy, lib_path=None):
         import ctypes as C
@@ -128,19 +135,28 @@ class FusedMinibatchGrad:
         from .params import R6PolicyGrad, R6PolicyNet
 
         if not self.supports(policy):
-            raise ValueError("FusedMinibatchGrad needs ActorCritic(net_arch=(128, 64), shared_trunk=True) on a GPU")
+            raise ValueError("FusedMinibatchGrad needs ActorCritic(net_arch=(128, 64), shared_trunk=True) or "
+                             "ActorCritic(net_arch=(64, 64), shared_trunk=False) on a GPU")
         self.lib = _lib.load(lib_path)
         pi = [m for m in policy.pi if isinstance(m, nn.Linear)]
-        vf_head = [m for m in policy.vf if isinstance(m, nn.Linear)][-1]
-        self.params = [pi[0].weight, pi[0].bias, pi[1].weight, pi[1].bias, pi[2].weight, pi[2].bias, vf_head.weight, vf_head.bias,
+        vf = [m for m in policy.vf if isinstance(m, nn.Linear)]
+        self.shared = bool(getattr(policy, "shared_trunk", False))
+        self.arch = (pi[0].out_features, pi[1].out_features)
+        self.params = [pi[0].weight, pi[0].bias, pi[1].weight, pi[1].bias, pi[2].weight, pi[2].bias, vf[2].weight, vf[2].bias,
                        policy.log_std]
+        self._net_names = ["pi_w1", "pi_b1", "pi_w2", "pi_b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"]
+        self._grad_names = ["w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"]
+        if not self.shared:      # the value MLP's own trunk
+            self.params += [vf[0].weight, vf[0].bias, vf[1].weight, vf[1].bias]
+            self._net_names += ["vf_w1", "vf_b1", "vf_w2", "vf_b2"]
+            self._grad_names += ["vf_w1", "vf_b1", "vf_w2", "vf_b2"]
         for t in self.params:
             if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError("policy parameters must be contiguous float32 CUDA tensors")
         self.device = self.params[0].device
         self.obs_dim = pi[0].in_features
         if {id(t) for t in self.params} != {id(t) for t in policy.parameters()}:
-            raise ValueError("the policy has parameters outside the shared trunk and its two heads")
+            raise ValueError("the policy has parameters outside its trunk(s) and two heads")
         # Parameters, gradients and Adam moments as FLAT arrays: every parameter becomes a view into one buffer (same
         # nn.Parameter objects, same state_dict), so the optimiser step is one launch over n floats (r6_adam_clip_step) and a
         # multi-rank gradient all-reduce is one bucket with no packing.
@@ -154,13 +170,13 @@ class FusedMinibatchGrad:
             t.data = self.flat_p[off:off + k].view_as(t)
             self.grads.append(self.flat_g[off:off + k].view_as(t))
             off += k
-        self.log_std_offset = off - sizes[-1]
+        self.log_std_offset = sum(sizes[:8])      # log_std is the ninth tensor of the flat arrays
         self.stats = torch.zeros(16, dtype=torch.float32, device=self.device)   # [0..7] last launch, [8..15] running sums
         self.norm = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._norm_scratch = torch.zeros(256, dtype=torch.float64, device=self.device)
         self.scratch = torch.empty(int(self.lib.r6_ppo_scratch_floats()), dtype=torch.float32, device=self.device)
         self._net, self._grad, self._C = R6PolicyNet(), R6PolicyGrad(), C
-        for name, t in zip(("w1", "b1", "w2", "b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.grads):
+        for name, t in zip(self._grad_names, self.grads):
             setattr(self._grad, name, t.data_ptr())
 
     def adam_step(self, lr, max_grad_norm: float, log_std_min=None, betas=(0.9, 0.999), eps: float = 1e-5):
@@ -206,8 +222,8 @@ class FusedMinibatchGrad:
         parameters' ``.grad`` and returns the stats tensor [pg_loss, v_loss, entropy, clip_frac, approx_kl, n, -, -] of this
         launch, followed by the running sums of the same eight over all launches since ``stats[8:]`` was last zeroed."""
         C, net = self._C, self._net
-        net.obs_dim, net.hidden1, net.hidden2, net.shared = self.obs_dim, self.ARCH[0], self.ARCH[1], 1
-        for name, t in zip(("pi_w1", "pi_b1", "pi_w2", "pi_b2", "pi_w3", "pi_b3", "vf_w3", "vf_b3", "log_std"), self.params):
+        net.obs_dim, net.hidden1, net.hidden2, net.shared = self.obs_dim, self.arch[0], self.arch[1], int(self.shared)
+        for name, t in zip(self._net_names, self.params):
             setattr(net, name, t.data_ptr())
         n = int(index.numel()) if index is not None else int(obs.shape[0])
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())

@@ -133,11 +133,13 @@ def test_fused_ppo_loss_matches_autograd():
         assert int(st[5]) == n
 
 
+@pytest.mark.parametrize("arch,shared", [((128, 64), True), ((64, 64), False)])
 @pytest.mark.parametrize("obs_dim,n_rows,n_mb,norm_adv", [(13, 5000, 3001, True), (14, 70000, 65536, False), (13, 300, 17, True)])
-def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv):
-    """r6_ppo_minibatch_grad -- forward, PPO loss and the whole backward pass of the reference's shared-trunk net
-    [128, 64] in one launch -- against torch autograd through the same modules on the same minibatch (rows picked by
-    index): every parameter gradient within 2e-5 of its tensor's largest entry, the loss statistics within 3e-5."""
+def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv, arch, shared):
+    """r6_ppo_minibatch_grad -- forward, PPO loss and the whole backward pass in one launch, for the reference's shared-trunk
+    net [128, 64] and for SB3's default two MLPs (64, 64) -- against torch autograd through the same modules on the same
+    minibatch (rows picked by index): every parameter gradient within 2e-5 of its tensor's largest entry, the loss
+    statistics within 3e-5."""
     import math
 
     import torch
@@ -146,7 +148,7 @@ def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv):
 
     torch.manual_seed(1)
     dev = "cuda"
-    pol = ActorCritic(obs_dim, 3, (128, 64), log_std_init=-0.3, shared_trunk=True).to(dev)
+    pol = ActorCritic(obs_dim, 3, arch, log_std_init=-0.3, shared_trunk=shared).to(dev)
     with torch.no_grad():                       # SB3's init makes the action head tiny (gain 0.01): scale it up so that its
         pol.pi[-1].weight.mul_(30.0)            # gradient path is not numerically negligible in the comparison
         pol.pi[-1].bias.uniform_(-0.2, 0.2)
@@ -193,7 +195,7 @@ def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv):
     for got, want in zip(st[:5].tolist(), want_stats):
         assert abs(got - float(want)) <= 3e-5 * max(1.0, abs(float(want))), (st.tolist(), [float(w) for w in want_stats])
     assert int(st[5]) == n_mb
-    print(f"[fused minibatch grad od={obs_dim} n={n_mb}] worst relative gradient error "
+    print(f"[fused minibatch grad {arch} shared={shared} od={obs_dim} n={n_mb}] worst relative gradient error "
           f"{max(float((p.grad - g).abs().max()) / max(float(g.abs().max()), 1e-12) for p, g in zip(params, g_ref)):.2e}")
 
 
