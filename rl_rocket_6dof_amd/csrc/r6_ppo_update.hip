@@ -845,6 +845,64 @@ __global__ __launch_bounds__(1024) void adam_clip_kernel(float* __restrict__ par
     if (threadIdx.x == 0) *step_dev = t;
 }
 
+// The same step for n <= K * 1024 (the policies here have ~10.4 k parameters): every thread fetches its K elements of grad, m, v
+// and param up front -- 4 K loads in flight, ONE memory round trip -- and keeps them in registers across the norm reduction.
+// The strided loops above pay a dependent round trip per iteration: 10.4 us for 10 311 parameters, a ninth of a fused PPO
+// minibatch step.
+template <int K>
+__global__ __launch_bounds__(1024) void adam_clip_small_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                                                               float* __restrict__ v, const int n, const float max_norm, const float lr_value,
+                                                               const float* __restrict__ lr_dev, const float beta1, const float beta2,
+                                                               const float eps, int64_t* __restrict__ step_dev, const int clamp_off,
+                                                               const int clamp_n, const float clamp_min) {
+    __shared__ double red[16];
+    __shared__ float coef_s;
+    float g[K], mm[K], vv[K], pp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = k * 1024 + threadIdx.x;
+        const bool in = i < n;
+        g[k] = in ? grad[i] : 0.0f;
+        mm[k] = in ? m[i] : 0.0f;
+        vv[k] = in ? v[i] : 0.0f;
+        pp[k] = in ? param[i] : 0.0f;
+    }
+    const int64_t t = *step_dev + 1;                       // torch.optim.Adam: step count starts at 1
+    const float lr = lr_dev ? *lr_dev : lr_value;
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ss += (double)g[k] * (double)g[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 16; ++k) tot += red[k];
+        const float total_norm = (float)sqrt(tot);
+        coef_s = (max_norm > 0.0f) ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;   // clip_grad_norm_: clamped to 1
+    }
+    __syncthreads();
+    const float coef = coef_s;
+    const float bc1 = 1.0f - powf(beta1, (float)t), bc2 = 1.0f - powf(beta2, (float)t);
+    const float step_size = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = k * 1024 + threadIdx.x;
+        if (i < n) {
+            const float gi = g[k] * coef;
+            const float mi = fmaf(beta1, mm[k], (1.0f - beta1) * gi);
+            const float vi = fmaf(beta2, vv[k], (1.0f - beta2) * gi * gi);
+            m[i] = mi;
+            v[i] = vi;
+            float p = pp[k] - step_size * mi / fmaf(sqrtf(vi), isq_bc2, eps);
+            if (i >= clamp_off && i < clamp_off + clamp_n) p = fmaxf(p, clamp_min);
+            param[i] = p;
+        }
+    }
+    if (threadIdx.x == 0) *step_dev = t;
+}
+
 }  // namespace r6u
 
 extern "C" int r6_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
@@ -854,8 +912,13 @@ extern "C" int r6_adam_clip_step(float* param, const float* grad, float* exp_avg
         r6_internal_set_error("r6_adam_clip_step: param, grad, exp_avg, exp_avg_sq, step_dev and n > 0 are required");
         return R6_E_BADARG;
     }
-    hipLaunchKernelGGL(r6u::adam_clip_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n,
-                       max_grad_norm, lr, lr_dev, beta1, beta2, eps, step_dev, clamp_off, clamp_n, clamp_min);
+    constexpr int kSmall = 12;
+    if (n <= kSmall * 1024)
+        hipLaunchKernelGGL(r6u::adam_clip_small_kernel<kSmall>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg,
+                           exp_avg_sq, (int)n, max_grad_norm, lr, lr_dev, beta1, beta2, eps, step_dev, (int)clamp_off, (int)clamp_n, clamp_min);
+    else
+        hipLaunchKernelGGL(r6u::adam_clip_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n,
+                           max_grad_norm, lr, lr_dev, beta1, beta2, eps, step_dev, clamp_off, clamp_n, clamp_min);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         r6_internal_set_error(hipGetErrorString(e));

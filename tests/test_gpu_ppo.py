@@ -271,3 +271,32 @@ def test_batched_advantage_norm_and_running_stats():
         st = fused(obs, act, old, adv, ret, perm[b * bs:(b + 1) * bs], batched[b], 0.2, 0.5, 0.0)
         tot += st[:6]
     assert float((fused.stats[8:14] - tot).abs().max()) <= 1e-5 * float(tot.abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 1000, 12288, 12289, 40000])
+def test_adam_clip_step_on_plain_arrays(n):
+    """Both kernels behind r6_adam_clip_step (register-resident for n <= 12 288, strided loops above) against
+    clip_grad_norm_ + Adam on one flat tensor."""
+    import ctypes as C
+
+    import torch
+
+    from rl_rocket_6dof_amd import _lib
+
+    lib = _lib.load()
+    torch.manual_seed(n)
+    p = torch.randn(n, device="cuda")
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    for it in range(3):
+        g = torch.randn(n, device="cuda") * (3.0 if it != 1 else 1e-3) / n ** 0.5
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        opt.step()
+        rc = lib.r6_adam_clip_step(vp(p), vp(g), vp(m), vp(v), n, 0.5, 1e-3, None, 0.9, 0.999, 1e-5, vp(step), 0, 0, 0.0, None)
+        _lib.check(rc, "r6_adam_clip_step", lib)
+        assert float((p - ref.detach()).abs().max()) <= 5e-7, (n, it)
+    assert int(step) == 3
