@@ -50,6 +50,7 @@ constexpr int kFeat = 2 * kFeatNet;        // room for two nets (a shared trunk 
 constexpr int kScalars = 16;               // db3[4], dlog_std[3], pg, v, clip_frac, kl (+ pad)
 constexpr int kOffFeat = kNumBlocks * 1024, kOffScal = kOffFeat + kFeat;
 constexpr int kPartial = kOffScal + kScalars;   // one workgroup's partial set: [blocks][feat][scalars]
+constexpr int kStampSlots = 20;            // R6U_STAMPS builds only
 constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -133,7 +134,9 @@ struct Args {
 #endif
 #define R6U_OPAQUE(p) asm volatile("" : "+v"(p))
 #ifdef R6U_STAMPS
-#define R6U_MARK(k) do { if (tid == 0 && blockIdx.x == 0) { const uint64_t now_ = wall_clock64(); partial[(int64_t)gridDim.x * kPartial + (k)] += (float)(now_ - mark_); mark_ = now_; } } while (0)
+// phase stamps of wave 0's last tile: raw 100 MHz ticks into kStampSlots extra floats of LDS behind the staging areas, copied out
+// by workgroup 0 after the tile loop -- one s_memrealtime + ds_write each, cheap enough not to disturb the loop's registers
+#define R6U_MARK(k) do { if (wave == 0) lds[Im::kTotal + (k)] = __uint_as_float((uint32_t)wall_clock64()); } while (0)
 #else
 #define R6U_MARK(k) do { } while (0)
 #endif
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             retv = a.ret[row];
         }
 #ifdef R6U_STAMPS
-        uint64_t mark_ = wall_clock64();
+        R6U_MARK(0);
 #endif
         // ---- forward: one net after the other (the two MLPs share nothing but x) ------------------------------------------
         f32x16 a1[NETS][B1], a2[NETS][B2];
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     for (int s = 0; s < 16; ++s) acc[iW2(ni, 1, ib)] = mfma(op[1][s], ba[s], acc[iW2(ni, 1, ib)]);
                     R6U_CHAIN_FENCE();
                 }
-                R6U_MARK(5);   // G2
+                R6U_MARK(5 + 3 * ib);   // G2
                 // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
                 f32x16 d1;
 #pragma unroll
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 R6U_CHAIN_FENCE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ni][ib][r], a1[ni][ib][r], 1.0f);
-                R6U_MARK(6);   // B2
+                R6U_MARK(6 + 3 * ib);   // B2
                 wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     for (int s = 0; s < 16; ++s) acc[iW1(ni, ib)] = mfma(op[0][s], (col < 16) ? bx[s] : 0.0f, acc[iW1(ni, ib)]);
                     R6U_CHAIN_FENCE();
                 }
-                R6U_MARK(7);   // G1
+                R6U_MARK(7 + 3 * ib);   // G1
             }
         }
     }
@@ -571,6 +574,10 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         out[kOffScal + 12] = (float)(ts1 - ts0);
         out[kOffScal + 13] = (float)(ts2 - ts1);
         out[kOffScal + 14] = (float)(wall_clock64() - ts2);
+    }
+    if (tid < kStampSlots && blockIdx.x == 0) {   // differences to the tile's first stamp, behind the last workgroup's partial set
+        const uint32_t t0 = __float_as_uint(lds[Im::kTotal]), tk = __float_as_uint(lds[Im::kTotal + tid]);
+        partial[(int64_t)gridDim.x * kPartial + tid] = (float)(tk - t0);
     }
 #endif
 }
@@ -657,7 +664,11 @@ template <int NETS, int H1, int H2, int OD>
 int launch(const R6PolicyNet& net, const Args& a, const R6PolicyGrad& gr, float* stats, float* scratch, size_t scratch_floats,
            hipStream_t s) {
     auto kernel = ppo_grad_kernel<NETS, H1, H2, OD>;
+#ifdef R6U_STAMPS
+    constexpr size_t lds_bytes = sizeof(float) * (Image<NETS, H1, H2>::kTotal + kStampSlots);
+#else
     constexpr size_t lds_bytes = sizeof(float) * Image<NETS, H1, H2>::kTotal;
+#endif
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     static std::atomic<bool> configured[16];

@@ -25,8 +25,11 @@ f.scratch.zero_()
 for _ in range(reps):
     f(obs, act, old, adv, ret, mb, None, 0.2, 0.5, 0.0)
 torch.cuda.synchronize()
-st = f.scratch[nw * P:nw * P + 8].cpu() / reps / 100.0
-names = ["F1", "F2", "heads+loss", "G3+staging", "delta2+db2", "G2 x4", "B2 x4", "G1 x4"]
-co = f.scratch[:nw * P].view(nw, P)[:, P - 4:P - 1].cpu() / 100.0   # last launch: per workgroup
-print("us per launch (mean over workgroups, wave 0): image staging %.1f, tiles %.1f, workgroup reduction + write %.1f" % tuple(co.mean(0).tolist()))
-print("us per tile:", ", ".join(f"{n} {v:.2f}" for n, v in zip(names, st.tolist())), "| sum %.1f" % float(st.sum()))
+st = f.scratch[nw * P:nw * P + 20].cpu() / 100.0      # us since the tile's first stamp
+names = ["start", "forward", "heads+loss", "dW3 sums", "delta2+db2"] + [f"{p}[{ib}]" for ib in range(4) for p in ("G2", "B2", "G1")]
+prev = 0.0
+out = []
+for n_, v in zip(names[1:], st.tolist()[1:17]):
+    out.append(f"{n_} {v - prev:.2f}")
+    prev = v
+print("us per phase of wave 0's last tile (an R6U_STAMPS build spills: relative sizes only):", ", ".join(out), "| tile %.1f" % prev)
