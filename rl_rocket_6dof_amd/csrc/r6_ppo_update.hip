@@ -255,11 +255,45 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     }
 
     const int64_t n_tiles = (a.n + 31) >> 5;
+    // The gathers of a tile (its 32 rows of obs / action / old_logp / adv / ret, found through the index) are two dependent
+    // memory round trips, and nobody hides them at one wave per SIMD: 1 us of a 21 us tile while the rollout buffer sits in
+    // L2, several when it is 2^24 rows in HBM.  So they run one tile ahead: the next tile's row number is requested at the
+    // top of a tile, its data after the loss (those registers are free during the backward pass), and both are consumed
+    // in the next trip.  Row -1 = no sample (padding lane or no further tile).
+    const int64_t t_stride = (int64_t)gridDim.x * kWaves;
+    auto fetch_row = [&](int64_t tt) __attribute__((always_inline)) -> int {
+        const int64_t sidx = tt * 32 + col;
+        return (tt < n_tiles && sidx < a.n) ? (int)(a.index ? a.index[sidx] : sidx) : -1;
+    };
+    auto fetch_data = [&](int r, float (&x)[8], float (&sv)[6]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = 2 * s + h;
+            x[s] = 0.0f;
+            if (r >= 0) {
+                if (k < OD) x[s] = a.obs[(int64_t)r * OD + k];
+                else if (k == OD) x[s] = 1.0f;   // the bias column
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sv[q] = 0.0f;
+        if (r >= 0) {
+            sv[0] = a.action[3 * (int64_t)r + 0];
+            sv[1] = a.action[3 * (int64_t)r + 1];
+            sv[2] = a.action[3 * (int64_t)r + 2];
+            sv[3] = a.old_logp[r];
+            sv[4] = a.adv[r];
+            sv[5] = a.ret[r];
+        }
+    };
+    const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
+    int row_cur = fetch_row(t_first), row_next = fetch_row(t_first + t_stride);
+    float xk[8], sv[6];   // x: this lane's 8 features k = 2s + h of its sample (B operand of layer 1); sv: action[3], old_logp, adv, ret
+    fetch_data(row_cur, xk, sv);
 #pragma unroll 1
-    for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles; t += (int64_t)gridDim.x * kWaves) {
-        const int64_t si = t * 32 + col;
-        const bool live = si < a.n;
-        const int64_t row = live ? (a.index ? a.index[si] : si) : 0;
+    for (int64_t t = t_first; t < n_tiles; t += t_stride) {
+        const bool live = row_cur >= 0;
+        const int row_after = fetch_row(t + 2 * t_stride);   // arrives during this tile; becomes row_next at the bottom
 
         R6U_OPAQUE(q_w3);
         R6U_OPAQUE(q_b2);
@@ -274,31 +308,10 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         float* tw_base = lds + o_tw;
         const float* tr_base = lds + (q_tr << 2);
         float* stat_base = lds + o_stat;
-        // ---- x: this lane's 8 features k = 2s + h of its sample (B operand of layer 1), bias column k == OD = 1 --------
-        float xk[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = 2 * s + h;
-            xk[s] = 0.0f;
-            if (live) {
-                if (k < OD) xk[s] = a.obs[row * OD + k];
-                else if (k == OD) xk[s] = 1.0f;
-            }
-        }
-
         wave_sync();   // the previous tile's readers of the staging area are done
 #pragma unroll
         for (int s = 0; s < 8; ++s) tw_base[Im::sX + (2 * s - 3 * h) * kPitch] = xk[s];   // row 2s + h (tw_base sits at row 4h)
-        // the scalars of the loss: fetched now, needed after layer 2 (one wave per SIMD: nobody hides a gather's latency later)
-        float act0 = 0.0f, act1 = 0.0f, act2 = 0.0f, olp = 0.0f, advv = 0.0f, retv = 0.0f;
-        if (live) {
-            act0 = a.action[3 * row + 0];
-            act1 = a.action[3 * row + 1];
-            act2 = a.action[3 * row + 2];
-            olp = a.old_logp[row];
-            advv = a.adv[row];
-            retv = a.ret[row];
-        }
+        const float act0 = sv[0], act1 = sv[1], act2 = sv[2], olp = sv[3], advv = sv[4], retv = sv[5];
 #ifdef R6U_STAMPS
         R6U_MARK(0);
 #endif
@@ -395,6 +408,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         }
 
         R6U_MARK(2);   // heads + loss
+        fetch_data(row_next, xk, sv);   // the next tile's rows: in flight during the backward pass
         if (h == 0) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) tw_base[Im::sG + o * kPitch] = g[o];
@@ -507,6 +521,8 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 R6U_MARK(7 + 3 * ib);   // G1
             }
         }
+        row_cur = row_next;
+        row_next = row_after;
     }
 
     // ---- workgroup reduction: scalars, per-feature sums, then the accumulator blocks four at a time through the staging areas ----
