@@ -50,7 +50,9 @@ constexpr int kFeat = 2 * kFeatNet;        // room for two nets (a shared trunk 
 constexpr int kScalars = 16;               // db3[4], dlog_std[3], pg, v, clip_frac, kl (+ pad)
 constexpr int kOffFeat = kNumBlocks * 1024, kOffScal = kOffFeat + kFeat;
 constexpr int kPartial = kOffScal + kScalars;   // one workgroup's partial set: [blocks][feat][scalars]
-constexpr int kStampSlots = 20;            // R6U_STAMPS builds only
+#ifdef R6U_STAMPS
+constexpr int kStampSlots = 20;
+#endif
 constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -200,7 +202,6 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #ifdef R6U_STAMPS
     const uint64_t ts1 = wall_clock64();
 #endif
-    float* st = lds + Im::kImage + wave * Im::kStage;   // this wave's staging area
     const int pcol = (col & 1) * 16 + (col >> 1);        // a sample's place in a transposed row: even samples first, then the odd ones
     const int hoff = h * 16;                             // the 16 places an MFMA chain of this lane half reads (sample 2s + h <-> h*16 + s)
     // One base register per access pattern, re-made opaque in every tile (R6U_OPAQUE): every LDS address below is then
