@@ -416,6 +416,11 @@ class PPO:
             self.fused_update = FusedMinibatchGrad(self.policy)
         self.fused = None
         self._rollout_step = 0
+        # launch-only rollout (set up below when the fused forward exists): time-limit bootstrap folded into r6_gae,
+        # env outputs written straight into the rollout buffer, the whole rollout replayed as a HIP graph
+        self._time_limit, self._direct, self._in_kernel_bootstrap = False, None, False
+        self.buf_flags = self.buf_boot = None
+        self._rollout_graph, self._rollouts = None, 0
         if cfg.fused_policy and self.device.type == "cuda":
             from .policy import FusedActorCritic
 
@@ -433,7 +438,6 @@ class PPO:
                 # env outputs land directly in the rollout buffer when its rows are 16-byte aligned (BatchedRocket6DOF.step_into)
                 self._direct = hasattr(env, "step_into") and (n * env.obs_dim) % 4 == 0 and not getattr(env, "numpy_io", False)
                 self._step_base = torch.zeros((), dtype=torch.int64, device=self.device)
-                self._rollout_graph, self._rollouts = None, 0
                 if self._direct:
                     env.set_step_base(self._step_base)
 
