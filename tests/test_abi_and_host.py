@@ -82,6 +82,21 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.r6_step_k(C.byref(p), C.byref(b), None, 0, 1, 0, None) == -10001          # no R6StepK
     assert lib.r6_step_k(C.byref(p), C.byref(b), C.byref(R6StepK(k=0)), 0, 1, 0, None) == -10001
     assert b"k must be" in lib.r6_last_error()
+    # the PPO-side entry points validate before they touch the device as well
+    from rl_rocket_6dof_amd.params import R6PolicyGrad, R6PolicyNet
+
+    assert lib.r6_gae(None, None, None, None, 4, 8, 0.99, 0.95, None, 4, None, None, None, None) == -10001
+    assert lib.r6_permutation(None, 16, 1, 1, None, None) == -10001
+    assert lib.r6_permutation(C.c_void_p(64), 0, 1, 1, None, None) == 0                  # empty: nothing to do, no launch
+    assert lib.r6_minibatch_adv_norm(C.c_void_p(64), None, 16, 0, C.c_void_p(64), C.c_void_p(64), None) == -10001   # n_batches = 0
+    assert lib.r6_adam_clip_step(None, None, None, None, 8, 0.5, 1e-3, None, 0.9, 0.999, 1e-5, None, 0, 0, 0.0, None) == -10001
+    net, grad = R6PolicyNet(), R6PolicyGrad()
+    net.obs_dim, net.hidden1, net.hidden2, net.shared = 13, 256, 64, 1                    # unsupported topology
+    fake = C.c_void_p(64)
+    assert lib.r6_ppo_minibatch_grad(C.byref(net), fake, fake, fake, fake, fake, None, 32, None, 0.2, 0.5, 0.0, C.byref(grad), fake, fake,
+                                     1 << 20, None) == -10001
+    assert b"supported nets" in lib.r6_last_error()
+    assert lib.r6_policy_act(C.byref(net), None, 32, None, None, None, None, 0, 1, None, 0, 0, None, 0, None) == -10001
 
 
 def test_derived_quantities_match_reference():
