@@ -140,6 +140,17 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int kBiasK = OD;   // the obs column that is set to 1 and multiplies b1
 
+    // masked evaluation (row_flags): a workgroup none of whose tiles holds a wanted row leaves before it stages the 43 KB weight
+    // image -- V(terminal observation) is asked for after EVERY rollout step and answered for a handful of steps per episode
+    if (row_flags) {
+        const int64_t n_tiles0 = (n + 31) >> 5;
+        bool want = false;
+        for (int64_t t = (int64_t)blockIdx.x * kWaves + wave; t < n_tiles0; t += (int64_t)gridDim.x * kWaves) {
+            const int64_t env = t * 32 + col;
+            want = want || (env < n && (row_flags[env] & flag_mask) != 0);
+        }
+        if (!__syncthreads_or(want)) return;
+    }
     // ---- stage the weights: torch Linear layout [out][in] fp32 -> split halves in fragment order in LDS ----
     _Float16* ldsh = reinterpret_cast<_Float16*>(lds);
     auto put_split = [&](int off_hi, int off_lo, int e, float v) __attribute__((always_inline)) {
