@@ -470,6 +470,12 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
             R6U_MARK(4);   // delta2 + db2
             // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) -------------------
+            float dT[2][16], bxc[16];   // delta2^T rows and x's row are the same for every block: fetched once per net and tile
+            ldv<16>(tr_base + Im::sT2, dT[0]);
+            ldv<16>(tr_base + Im::sT2 + 32 * kPitch, dT[1]);
+            ldv<16>(tr_base + Im::sX - col * kPitch + (col & 15) * kPitch, bxc);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bxc[s] = (col < 16) ? bxc[s] : 0.0f;
 #pragma unroll
             for (int ib = 0; ib < B1; ++ib) {
                 wave_sync();   // the block buffer's previous readers are done
@@ -478,18 +484,16 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 wave_sync();
                 // dW2[f2][i] += sum_s delta2[f2][s] a1[i][s]
                 // Each chain's operands are fetched while the chain before it runs (static_assert: B2 == 2).
-                float op[2][16], bx[16];
+                float op[2][16];
                 {
                     float ba[16];
                     ldv<16>(tr_base + Im::sBlk, ba);
-                    ldv<16>(tr_base + Im::sT2, op[0]);
-                    ldv<16>(tr_base + Im::sT2 + 32 * kPitch, op[1]);
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[iW2(ni, 0, ib)] = mfma(op[0][s], ba[s], acc[iW2(ni, 0, ib)]);
-                    R6U_CHAIN_FENCE();
                     ldv<16>(&lds[Im::oW2T + (((ni * B1 + ib) * B2 + 0) * 64 + lane) * kP2], op[0]);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[iW2(ni, 1, ib)] = mfma(op[1][s], ba[s], acc[iW2(ni, 1, ib)]);
+                    for (int s = 0; s < 16; ++s) acc[iW2(ni, 0, ib)] = mfma(dT[0][s], ba[s], acc[iW2(ni, 0, ib)]);
+                    R6U_CHAIN_FENCE();
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) acc[iW2(ni, 1, ib)] = mfma(dT[1][s], ba[s], acc[iW2(ni, 1, ib)]);
                     R6U_CHAIN_FENCE();
                 }
                 R6U_MARK(5 + 3 * ib);   // G2
@@ -501,7 +505,6 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1 = mfma(op[0][r], d2[0][r], d1);
                 R6U_CHAIN_FENCE();
-                ldv<16>(tr_base + Im::sX - col * kPitch + (col & 15) * kPitch, bx);   // x's row (col & 15): B of dW1 below
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1 = mfma(op[1][r], d2[1][r], d1);
                 R6U_CHAIN_FENCE();
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 {
                     ldv<16>(tr_base + Im::sBlk, op[0]);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[iW1(ni, ib)] = mfma(op[0][s], (col < 16) ? bx[s] : 0.0f, acc[iW1(ni, ib)]);
+                    for (int s = 0; s < 16; ++s) acc[iW1(ni, ib)] = mfma(op[0][s], bxc[s], acc[iW1(ni, ib)]);
                     R6U_CHAIN_FENCE();
                 }
                 R6U_MARK(7 + 3 * ib);   // G1
