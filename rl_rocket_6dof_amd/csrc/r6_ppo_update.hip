@@ -19,7 +19,8 @@
 //   weight gradients  dW2 = delta2 a1^T, dW1 = delta1 x^T, dW3 = g a2^T, db2 = delta2 1: products that CONTRACT OVER
 //             THE SAMPLES, i.e. over the lane dimension of everything above.  The tiles are transposed through a per-wave
 //             LDS buffer ([feature][sample], pitch 36) and read back as MFMA operands with the sample index on K; the
-//             sums live in accumulator registers (12 blocks of 32 x 32 per wave, 192 registers) for the whole launch.
+//             sums live in accumulator registers for the whole launch: dW2 in 8 blocks of 32 x 32 (128 registers), dW1 + db1
+//             (14 + 1 useful columns) in 8 blocks of 16 x 16 through v_mfma_f32_16x16x4_f32 (32 registers).
 //             dW3 and db2 (4 + 1 useful columns) are summed on the VALU instead, lane = layer-2 feature = a row of the tile.
 // After its last tile a workgroup adds its waves' blocks in LDS and writes one partial set; a second small launch sums
 // the partial sets of all workgroups and scatters them into torch's parameter layouts.
@@ -44,7 +45,8 @@ constexpr int kBlock = 256, kWaves = 4;
 constexpr int kPitch = 36;                 // floats per row of the transposed tiles: 32 samples (even ones first, then the odd ones) + 4,
                                            // 16-byte aligned rows whose 16-float halves are read conflict-free as 4 x ds_read_b128
 constexpr int kP2 = 20;                    // floats per lane of the layer-2 weight images (16 used): a conflict-free ds_read_b128 pitch
-constexpr int kNumBlocks = 12;             // 32x32 accumulator blocks per wave: dW2 (8) + dW1 (4), shared trunk [128, 64] or two MLPs (64, 64)
+constexpr int kNumBlocks = 12;             // 32x32 slots of a partial set: dW2 (8) + dW1 (4; accumulated as two 16x16 blocks each, left half of the
+                                           // slot), shared trunk [128, 64] or two MLPs (64, 64)
 constexpr int kFeatNet = 5 * 64;           // per net and layer-2 feature f: dW3^T[f][0..3] and db2[f], summed on the VALU with lane = feature
 constexpr int kFeat = 2 * kFeatNet;        // room for two nets (a shared trunk uses the first half)
 constexpr int kScalars = 16;               // db3[4], dlog_std[3], pg, v, clip_frac, kl (+ pad)
@@ -60,6 +62,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// 16 x 16 output, K = 4 per instruction (lane l: A row / B column l % 16, k = l / 16; D register r: row 4 (l / 16) + r, column l % 16):
+// the shape of dW1 = delta1 x^T, whose 14 + 1 useful columns fill a 16-wide block where the 32-wide one was half padding
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // tanh(z) = 1 - 2 / (exp(2z) + 1): v_exp_f32 + v_rcp_f32, absolute error ~1e-7, saturates cleanly
 __device__ __forceinline__ float tanh_fast(float z) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(kExpScale * z) + 1.0f), 1.0f);
@@ -218,6 +223,10 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     static_assert(Im::oB2 % 4 == 0, "16-byte aligned rows");
     int q_b2 = (Im::oB2 + h * 16) >> 2;
     int o_tw = stage0 + 4 * h * kPitch + pcol;           // writes of transposed tiles: element (row(r, h), sample)
+    // delta1 and x feed the 16x16x4 product: there a lane group g = l / 16 contracts the samples g, g + 4, ..., g + 28, so their
+    // rows keep sample s at place (s % 4) * 8 + s / 4 (8 consecutive floats per group = 2 ds_read_b128)
+    int o_tw4 = stage0 + 4 * h * kPitch + (col & 3) * 8 + (col >> 2);
+    int q_tr4 = (stage0 + (lane & 15) * kPitch + (lane >> 4) * 8) >> 2;   // reads: row l % 16 (+ 16 for the second block), group l / 16
     int q_tr = (stage0 + col * kPitch + hoff) >> 2;      // reads of row `col`, this lane half's 16 samples
     // wave-uniform scalars live in SGPRs (readfirstlane: the compiler keeps a computed float in a VGPR otherwise)
     auto uni = [](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -237,9 +246,9 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     for (int k = 0; k < 11; ++k) lds[o_stat + k * 64 * kP2] = 0.0f;
 
     // ---- accumulators of the launch -----------------------------------------------------------------------------------
-    f32x16 acc[kNumBlocks];                                  // net-major: dW2 [mb][ib] (iW2), then dW1 [ib] (iW1)
-    auto iW2 = [](int ni, int mb, int ib) __attribute__((always_inline)) { return ni * kNetBlocks + mb * B1 + ib; };
-    auto iW1 = [](int ni, int ib) __attribute__((always_inline)) { return ni * kNetBlocks + B2 * B1 + ib; };
+    f32x16 acc[NETS * B2 * B1];                              // dW2 [net][mb][ib]
+    f32x4 acc1[NETS * B1][2];                                // dW1 [net][ib]: two 16 x 16 blocks (rows 0..15, 16..31 of the 32-feature block)
+    auto iW2 = [](int ni, int mb, int ib) __attribute__((always_inline)) { return (ni * B2 + mb) * B1 + ib; };
     float f_w3[NETS][4], f_b2[NETS];                         // lane = layer-2 feature: dW3^T[lane][0..3], db2[lane]
 #pragma unroll
     for (int ni = 0; ni < NETS; ++ni) {
@@ -250,9 +259,14 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     int q_fr = (stage0 + lane * kPitch) >> 2;                // row `lane` of the transposed a2 / delta2 tile
     int q_g = (stage0 + Im::sG) >> 2;                        // g's four rows (the same address in every lane: LDS broadcast)
 #pragma unroll
-    for (int k = 0; k < kNumBlocks; ++k) {
+    for (int k = 0; k < NETS * B2 * B1; ++k) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < NETS * B1; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1[k][0][r] = acc1[k][1][r] = 0.0f;
     }
 
     const int64_t n_tiles = (a.n + 31) >> 5;
@@ -299,6 +313,8 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         R6U_OPAQUE(q_w3);
         R6U_OPAQUE(q_b2);
         R6U_OPAQUE(o_tw);
+        R6U_OPAQUE(o_tw4);
+        R6U_OPAQUE(q_tr4);
         R6U_OPAQUE(q_tr);
         R6U_OPAQUE(o_stat);
         R6U_OPAQUE(q_fr);
@@ -307,11 +323,13 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         const float* w3_base = lds + (q_w3 << 2);
         const float* b2_base = lds + (q_b2 << 2);
         float* tw_base = lds + o_tw;
+        float* tw4_base = lds + o_tw4;
+        const float* tr4_base = lds + (q_tr4 << 2);
         const float* tr_base = lds + (q_tr << 2);
         float* stat_base = lds + o_stat;
         wave_sync();   // the previous tile's readers of the staging area are done
 #pragma unroll
-        for (int s = 0; s < 8; ++s) tw_base[Im::sX + (2 * s - 3 * h) * kPitch] = xk[s];   // row 2s + h (tw_base sits at row 4h)
+        for (int s = 0; s < 8; ++s) tw4_base[Im::sX + (2 * s - 3 * h) * kPitch] = xk[s];   // row 2s + h (the base sits at row 4h)
         const float act0 = sv[0], act1 = sv[1], act2 = sv[2], olp = sv[3], advv = sv[4], retv = sv[5];
 #ifdef R6U_STAMPS
         R6U_MARK(0);
@@ -470,12 +488,10 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
             R6U_MARK(4);   // delta2 + db2
             // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) -------------------
-            float dT[2][16], bxc[16];   // delta2^T rows and x's row are the same for every block: fetched once per net and tile
+            float dT[2][16], bxc[8];   // delta2^T rows and x's row are the same for every block: fetched once per net and tile
             ldv<16>(tr_base + Im::sT2, dT[0]);
             ldv<16>(tr_base + Im::sT2 + 32 * kPitch, dT[1]);
-            ldv<16>(tr_base + Im::sX - col * kPitch + (col & 15) * kPitch, bxc);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) bxc[s] = (col < 16) ? bxc[s] : 0.0f;
+            ldv<8>(tr4_base + Im::sX, bxc);   // x's row l % 16, samples g, g + 4, ...: B of the 16x16x4 product below
 #pragma unroll
             for (int ib = 0; ib < B1; ++ib) {
                 wave_sync();   // the block buffer's previous readers are done
@@ -513,14 +529,19 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 R6U_MARK(6 + 3 * ib);   // B2
                 wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
+                for (int r = 0; r < 16; ++r) tw4_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
                 wave_sync();
-                // dW1[i][k] += sum_s delta1[i][s] x[k][s]   (k == OD: db1, through x's column of ones)
+                // dW1[i][k] += sum_s delta1[i][s] x[k][s]   (k == OD: db1, through x's column of ones): 16x16x4, two row blocks
                 {
-                    ldv<16>(tr_base + Im::sBlk, op[0]);
+                    float t0[8], t1[8];
+                    ldv<8>(tr4_base + Im::sBlk, t0);
+                    ldv<8>(tr4_base + Im::sBlk + 16 * kPitch, t1);
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[iW1(ni, ib)] = mfma(op[0][s], bxc[s], acc[iW1(ni, ib)]);
-                    R6U_CHAIN_FENCE();
+                    for (int j = 0; j < 8; ++j) {
+                        acc1[ni * B1 + ib][0] = mfma16(t0[j], bxc[j], acc1[ni * B1 + ib][0]);
+                        acc1[ni * B1 + ib][1] = mfma16(t1[j], bxc[j], acc1[ni * B1 + ib][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 R6U_MARK(7 + 3 * ib);   // G1
             }
@@ -581,12 +602,28 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     };
     static_assert(Im::kStage >= 4 * 1024, "a wave's staging area holds four accumulator blocks");
     __syncthreads();
-    // the 12 blocks in their net-major order, four per round
+    // dW1's 16 x 16 blocks go into the left half of a 32 x 32 slot (the right half, never read, is zeroed)
+    auto put16 = [&](const f32x4 (&a2x)[2], int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m2 * 16 + 4 * (lane >> 4) + r;
+                slab[slot * 1024 + m * 32 + (lane & 15)] = a2x[m2][r];
+                slab[slot * 1024 + m * 32 + 16 + (lane & 15)] = 0.0f;
+            }
+        }
+    };
+    // the 12 blocks in their net-major order (per net: dW2 [mb][ib], then dW1 [ib]), four per round
     static_assert(kNumBlocks % 4 == 0, "whole rounds");
 #pragma unroll
     for (int round = 0; round < kNumBlocks / 4; ++round) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) put(acc[round * 4 + k], k);
+        for (int k = 0; k < 4; ++k) {
+            const int blk = round * 4 + k, ni = blk / kNetBlocks, loc = blk % kNetBlocks;
+            if (loc < B2 * B1) put(acc[ni * B2 * B1 + loc], k);
+            else put16(acc1[ni * B1 + (loc - B2 * B1)], k);
+        }
         drain(round * 4, 4);
     }
 #ifdef R6U_STAMPS
