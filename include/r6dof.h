@@ -274,7 +274,8 @@ int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std
  * value head (R6PolicyNet.shared = 1, hidden (128, 64)), and SB3's default, two separate tanh MLPs obs -> 64 -> 64
  * (shared = 0, hidden (64, 64); BASELINE configs[4] "SB3 PPO MLP(64,64)").
  *   obs (rows, obs_dim), action (rows, 3), old_logp / adv / ret [rows]: the rollout buffer; `index` [n] (int64, or NULL for
- *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
+ *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  Row numbers must be below 2^31 (they are kept as
+ *   32-bit values one tile ahead of their use).  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
  *   grad: WRITTEN (not accumulated), torch.nn.Linear layouts like the weights.  stats [16]: [0..7] written: pg_loss, v_loss,
  *   entropy, clip_frac, approx_kl, n; [8..15] += the same six (running sums over launches: the caller zeroes them when a new sum
  *   starts and reads means once per update).  scratch: r6_ppo_scratch_floats() floats of device memory owned by the caller. */
