@@ -158,6 +158,29 @@ def traffic_from_profile(variant: str, integrator: str, n: int, k: int):
         return None, None
 
 
+VALU_PROFILE = os.path.join("profiles", "r2_pmc_valu.json")
+SIMDS, ENGINE_CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+
+
+def valu_from_profile(variant: str, integrator: str, n: int, k: int, kernel_ms: float):
+    """The kernel's OTHER limiter next to HBM: share of the launch in which a SIMD issues a VALU instruction, from the
+    committed PMC pass of THIS workload (SQ_ACTIVE_INST_VALU, quad-cycles per launch; scripts/pmc.sh) and this run's kernel
+    time.  A file constant like `traffic`; the clock is taken at its 2.4 GHz peak, so the share is a lower bound."""
+    path = os.path.join(ROOT, VALU_PROFILE)
+    if not (os.path.exists(path) and variant == "raw" and integrator == "rk4" and n == (1 << 20) and k == 1 and kernel_ms > 0):
+        return None
+    try:
+        prof = json.load(open(path))
+        active = float(prof["raw_per_launch"]["SQ_ACTIVE_INST_VALU"])
+        return {"busy_frac": 4.0 * active / SIMDS / (ENGINE_CLOCK_HZ * kernel_ms * 1e-3),
+                "instructions_per_64_env_tile": prof["derived"]["valu_instructions_per_64_env_tile"],
+                "source": f"{VALU_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); engine clock "
+                          f"assumed at its {ENGINE_CLOCK_HZ / 1e9:.1f} GHz peak",
+                "note": "the step kernel is co-bound: VALU issue and HBM are each busy for about two thirds of a launch"}
+    except Exception:
+        return None
+
+
 def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: float, *, traffic=None, traffic_source=None,
                extras=None) -> dict:
     """The ONE JSON line of the bench contract from the reduced measurements (pure function: testable without a GPU).
@@ -334,6 +357,9 @@ def main(argv=None):
     if rank == 0:
         dt = args.dt or cfg["timestep"]
         traffic, source = traffic_from_profile(args.variant, args.integrator, n, args.k)
+        valu = valu_from_profile(args.variant, args.integrator, n, args.k, kernel_ms)
+        if valu is not None:
+            extras["valu"] = valu
         if not multi and not args.no_extras:
             del env, pool
             torch.cuda.empty_cache()

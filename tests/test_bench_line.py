@@ -94,3 +94,16 @@ def test_two_rank_line_over_gloo():
     assert l0["rccl"]["rccl_ranks"] == 2 and l0["rccl"]["backend"] == "gloo"
     assert l0["rccl"]["with_rollout_gather"]["episodes_seen"] == 3.0
     assert l0["roofline"]["traffic"] is None and l0["roofline"]["traffic_source"] is None
+
+
+def test_valu_object_from_the_committed_profile():
+    """bench.py's `valu` object (the step kernel's second limiter): derived from profiles/r2_pmc_valu.json and the run's
+    kernel time, only for the profiled workload, and labelled as a static file."""
+    import bench
+
+    v = bench.valu_from_profile("raw", "rk4", 1 << 20, 1, 0.0375)
+    assert v is not None and 0.5 < v["busy_frac"] < 1.0 and "static file" in v["source"]
+    assert 900 < v["instructions_per_64_env_tile"] < 1000
+    assert bench.valu_from_profile("raw", "euler", 1 << 20, 1, 0.0375) is None
+    assert bench.valu_from_profile("raw", "rk4", 1 << 16, 1, 0.0375) is None
+    assert bench.valu_from_profile("raw", "rk4", 1 << 20, 16, 0.0375) is None
