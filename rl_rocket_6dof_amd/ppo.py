@@ -205,10 +205,12 @@ class FusedMinibatchGrad:
         if n_batches == 1:
             out, scratch = self.norm, self._norm_scratch
         else:
-            if getattr(self, "_norms", None) is None or self._norms.shape[0] != n_batches:
-                self._norms = torch.zeros((n_batches, 2), dtype=torch.float32, device=self.device)
-                self._norms_scratch = torch.zeros(256 * n_batches, dtype=torch.float64, device=self.device)
-            out, scratch = self._norms, self._norms_scratch
+            # one pair of buffers per batch count, never freed: a recorded graph keeps reading the ones it was captured with
+            cache = self.__dict__.setdefault("_norm_bufs", {})
+            if n_batches not in cache:
+                cache[n_batches] = (torch.zeros((n_batches, 2), dtype=torch.float32, device=self.device),
+                                    torch.zeros(256 * n_batches, dtype=torch.float64, device=self.device))
+            out, scratch = cache[n_batches]
         with torch.cuda.device(self.device):
             rc = self.lib.r6_minibatch_adv_norm(C.c_void_p(adv.data_ptr()), None if index is None else C.c_void_p(index.data_ptr()),
                                                 total // n_batches, n_batches, C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()),
@@ -704,6 +706,10 @@ class PPO:
                 n_batches += steps
                 continue
             perm = self._permute(self._perm_buf) if fast else torch.randperm(total, device=self.device, generator=self.gen)
+            norms = None
+            if self.fused_update is not None and cfg.normalize_advantage and bs > 1 and steps > 1:
+                # eager steps (multi-rank runs, warm-up): the epoch's advantage normalisations in one batched call all the same
+                norms = self.fused_update.adv_norm(flat[3], perm[:steps * bs], steps).view(steps, 2)
             s = 0
             while s < steps:
                 # the first steps run eagerly (allocator / Adam state warm-up), and so does the rest of that epoch when
@@ -715,7 +721,7 @@ class PPO:
                     s += chunk
                     n_batches += chunk
                 else:
-                    self._minibatch_step(perm[s * bs:(s + 1) * bs], flat, acc)
+                    self._minibatch_step(perm[s * bs:(s + 1) * bs], flat, acc, None if norms is None else norms[s])
                     self._eager_steps += 1
                     s += 1
                     n_batches += 1
