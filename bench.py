@@ -294,6 +294,16 @@ def main(argv=None):
     # R6_DIST_BACKEND=gloo + R6_FORCE_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
     # (RCCL refuses two ranks per device); the driver's real runs use the defaults (nccl, LOCAL_RANK).
     rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
+    # R6_FORCE_PROCESS_GROUP=1: a process group of ONE rank (backend nccl = RCCL by default) and the N > 1 code path on it --
+    # every collective of that path (device barrier, all-gathers of times and episode summaries) then really goes through
+    # RCCL on the one GPU a builder has; the numbers are those of a 1-GPU run
+    force_pg = world == 1 and os.environ.get("R6_FORCE_PROCESS_GROUP") == "1"
+    if force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("R6_FORCE_DEVICE", local)))
+        dist.init_process_group(backend=os.environ.get("R6_DIST_BACKEND") or "nccl", rank=0, world_size=1)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -301,16 +311,16 @@ def main(argv=None):
     local = int(os.environ.get("R6_FORCE_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    backend = dist.get_backend() if world > 1 else None
+    backend = dist.get_backend() if (world > 1 or force_pg) else None
     on_gpu_pg = backend == "nccl"
 
     n = args.envs_per_gpu
     cfg = default_env_config()
     wrapped = args.variant == "wrapped"
-    multi = world > 1
+    multi = world > 1 or force_pg
     env = BatchedRocket6DOF(
         n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=rank * n, auto_reset=True,
-        record_flags=False, record_terms=False, track_episodes=wrapped or multi,
+        record_flags=False, record_terms=False, track_episodes=wrapped,     # the headline workload is the same at every N
         remove_mass=wrapped, clip_reward=(-1, 100) if wrapped else None,
         max_episode_steps=int(150 / (args.dt or cfg["timestep"])) if wrapped else 0, seed=42)
     pool = make_pool(torch, n, args.k, args.pool, dev, 1234 + rank)
@@ -323,11 +333,20 @@ def main(argv=None):
             env.step_k(pool[j % args.pool], last_only=True)
         env._bench_out = env.step_k(pool[0])
 
+    # The barriers around the HEADLINE loop go through a gloo group: a live RCCL communicator on the device makes the very
+    # same step kernel 2 us slower per launch (37.5 -> 39.6 us, measured with one rank in one process, R6_FORCE_PROCESS_GROUP=1),
+    # and torch creates the communicator at the first RCCL collective -- so RCCL first runs after the headline's timed region
+    # (the reductions of the times, the rollout-gather loop and its barriers), and the raw step is timed alike at every N.
+    host_group = dist.new_group(backend="gloo") if (multi and on_gpu_pg) else None
+    rccl_live = [False]
+
     def barrier():
         torch.cuda.synchronize(dev)
         if multi:
-            if on_gpu_pg:
+            if on_gpu_pg and rccl_live[0]:
                 dist.barrier(device_ids=[local])     # RCCL: name the device, or the barrier guesses it from the rank
+            elif on_gpu_pg:
+                dist.barrier(group=host_group)
             else:
                 dist.barrier()
         torch.cuda.synchronize(dev)
@@ -338,14 +357,28 @@ def main(argv=None):
 
     extras = {}
     if multi:
+        rccl_live[0] = True
         red = r6dist.reduce_bench_times(wall, kernel_ms, device=dev)
         wall, kernel_ms = red["wall_max"], red["kernel_ms_max"]
         # the one collective of the design (episode summaries) inside a second, short timed loop:
         # BASELINE configs[4]'s per-rollout exchange
         gsteps = max(args.gather_every, min(args.steps, 10 * args.gather_every) // args.gather_every * args.gather_every)
         gathers = []     # per-rank tables stay on the device: the all-gather is stream-ordered, the loop never drains the GPU
-        wall_g, _ = timed_loop(env, pool, gsteps, args.k, barrier, stream, torch,
-                               every=(args.gather_every, lambda: gathers.append(r6dist.gather_episode_stats_device(env.episode_stats_tensor()))))
+        # its own env, with the episode accounting the summaries come from (ep_step / ep_return rows, +16 B per env-step and
+        # the statistics: ~45 us per step against the headline's ~38): the headline loop above stays the raw step at every N,
+        # so that the driver's scaling ratios compare like with like
+        env_g = env if wrapped else BatchedRocket6DOF(
+            n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=rank * n, auto_reset=True,
+            record_flags=False, record_terms=False, track_episodes=True, seed=42)
+        if env_g is not env:
+            env_g.reset()
+            for j in range(min(args.burnin, 400)):
+                env_g.step_async(pool[j % args.pool]) if args.k <= 1 else None
+            if args.k > 1:
+                env_g.step_k(pool[0], last_only=True)
+                env_g._bench_out = env_g.step_k(pool[0])
+        wall_g, _ = timed_loop(env_g, pool, gsteps, args.k, barrier, stream, torch,
+                               every=(args.gather_every, lambda: gathers.append(r6dist.gather_episode_stats_device(env_g.episode_stats_tensor()))))
         redg = r6dist.reduce_bench_times(wall_g, 0.0, device=dev)
         extras["rccl"] = {"backend": backend, "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
                           "kernel_us_min": red["kernel_ms_min"] * 1e3, "kernel_us_max": red["kernel_ms_max"] * 1e3,

@@ -18,6 +18,14 @@ import torch.distributed as dist
 from .params import NUM_STATS, STAT_NAMES
 
 
+def _collectives_on() -> bool:
+    """True when a process group exists and has more than one rank -- or has one rank and R6_FORCE_PROCESS_GROUP=1 asks for
+    the collectives all the same (a builder's rehearsal of the RCCL calls on a single GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("R6_FORCE_PROCESS_GROUP") == "1"
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """(offset, count) of rank's contiguous shard; counts differ by at most one."""
     if not (0 <= rank < world):
@@ -49,7 +57,7 @@ def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str
     """All-gathers the per-rank episode summaries (``BatchedRocket6DOF.episode_stats()``).
     Returns (global totals, per-rank table [world, NUM_STATS])."""
     vec = torch.tensor([local[k] for k in STAT_NAMES], dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         if dist.get_backend() == "nccl":
             vec = vec.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         rows = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
@@ -66,7 +74,7 @@ def gather_episode_stats_device(vec: torch.Tensor) -> torch.Tensor:
     (``BatchedRocket6DOF.episode_stats_tensor``): returns the per-rank table [world, NUM_STATS] on the same device.
     Under RCCL (backend nccl) nothing touches the host -- the collective is stream-ordered behind the kernels that
     produced the sums, so a rollout loop can issue it without draining the GPU; gloo goes through the host."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _collectives_on():
         return vec.reshape(1, -1)
     world = dist.get_world_size()
     if dist.get_backend() == "nccl":
@@ -84,7 +92,7 @@ def reduce_bench_times(wall_s: float, kernel_ms: float, device=None) -> Dict[str
     RCCL (backend nccl), on the host for gloo; the identity without a process group."""
     dev_index = torch.cuda.current_device() if torch.cuda.is_available() else -1
     vec = torch.tensor([wall_s, kernel_ms, float(dev_index)], dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         if dist.get_backend() == "nccl":
             vec = vec.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         rows = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
