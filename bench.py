@@ -337,8 +337,15 @@ def main(argv=None):
     # same step kernel 2 us slower per launch (37.5 -> 39.6 us, measured with one rank in one process, R6_FORCE_PROCESS_GROUP=1),
     # and torch creates the communicator at the first RCCL collective -- so RCCL first runs after the headline's timed region
     # (the reductions of the times, the rollout-gather loop and its barriers), and the raw step is timed alike at every N.
-    host_group = dist.new_group(backend="gloo") if (multi and on_gpu_pg) else None
-    rccl_live = [False]
+    host_group, rccl_live = None, [False]
+    if multi and on_gpu_pg:
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: do not depend on the hostname resolving
+        try:
+            host_group = dist.new_group(backend="gloo")
+        except Exception as e:                                     # the same on every rank of the node: RCCL barriers then
+            print(f"[bench] gloo group unavailable ({e}); barriers through RCCL", file=sys.stderr)
+            rccl_live[0] = True
 
     def barrier():
         torch.cuda.synchronize(dev)
