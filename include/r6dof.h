@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define R6_ABI_VERSION 5
+#define R6_ABI_VERSION 6
 #define R6_STATE_DIM 14
 #define R6_ACTION_DIM 3
 #define R6_NUM_TERMS 8 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
@@ -133,10 +133,12 @@ typedef struct R6Buffers {
     float *fin_return;    /* [n]       out at done: episode return */
     uint32_t *fin_length; /* [n]       out at done: episode length */
     uint8_t *nfev;        /* [n]       out: RHS evaluations of the step (scipy sol.nfev), saturating at 255 */
-    double *stats;        /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out (float64: counts stay exact): per-workgroup running sums over
-                                       finished episodes (see R6_STAT_*): accumulated with LDS float
-                                       atomics inside a workgroup, then added to the workgroup's own row
-                                       (no global atomics); the caller sums the rows */
+    double *stats;        /* [R6_MAX_BLOCKS][R6_NUM_STATS] in/out: per-workgroup running sums over finished episodes (see
+                                       R6_STAT_*).  Inside a workgroup they are exact integer / fixed-point sums (LDS integer
+                                       atomics; the episode return and its square in units of 2^-16, returns clamped to
+                                       +-32767), added to the workgroup's own float64 row (no global atomics); the caller
+                                       sums the rows.  The totals are exact and therefore independent of arrival order,
+                                       launch shape and sharding */
     const uint64_t *step_base; /* [1]  in (device memory) or NULL: added to the `step_index` argument where the reset
                                        RNG is keyed.  A launch recorded into a HIP graph carries its by-value arguments
                                        for ever; with the counter's base in device memory a replayed rollout still draws
@@ -147,6 +149,14 @@ int r6_abi_version(void);
 size_t r6_params_size(void);   /* sizeof(R6Params), for binding self-checks */
 size_t r6_buffers_size(void);  /* sizeof(R6Buffers) */
 const char *r6_last_error(void);
+
+/* Launch-shape knobs of r6_step (process-wide; results never depend on them, only which wave computes which tile and how
+ * many launches carry a step).  Keys: "even_xcd_share" (share of the tiles given to the workgroups on even XCDs, < 0 = default),
+ * "tail_frac" (share of the tiles left to late-dispatched tail workgroups, 0 = none), "tail_tiles_per_wave",
+ * "split" (1: large shards run as two launches fork/joined on a library-owned stream), "split_frac", "split_min_tiles",
+ * "grid_blocks" (> 0 pins the persistent grid), "sweep" (tile order on odd steps, -1 = default).  The same knobs are read once
+ * from the environment: R6_EVEN_XCD_SHARE, R6_TAIL_FRAC, R6_TAIL_TPW, R6_SPLIT, R6_SPLIT_FRAC, R6_GRID_BLOCKS, R6_SWEEP. */
+int r6_tune(const char *key, double value);
 
 /* Rocket6DOF.step for n envs (rocket_env.py:201-231): denormalise action, integrate one env
  * step (fixed Euler/RK4 sub-steps, ground-event localisation, quaternion renormalise), bounds,

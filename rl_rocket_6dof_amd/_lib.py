@@ -9,13 +9,13 @@ import os
 
 from .params import R6Buffers, R6Params, R6PolicyGrad, R6PolicyNet, R6StepK
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad",
            "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad", "r6_minibatch_adv_norm", "r6_adam_clip_step",
-           "r6_gae", "r6_permutation")
+           "r6_gae", "r6_permutation", "r6_tune")
 
 
 class R6Error(RuntimeError):
@@ -70,6 +70,8 @@ def load(path: str | None = None):
     lib.r6_gae.restype = C.c_int
     lib.r6_permutation.argtypes = [vp, i64, u64, u64, vp, vp]
     lib.r6_permutation.restype = C.c_int
+    lib.r6_tune.argtypes = [C.c_char_p, C.c_double]
+    lib.r6_tune.restype = C.c_int
     if lib.r6_policy_grad_size() != C.sizeof(R6PolicyGrad):
         raise ImportError("R6PolicyGrad layout mismatch between params.py and libr6dof.so: rebuild")
     for name in ("r6_step", "r6_step_k", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):
@@ -92,3 +94,9 @@ def check(rc: int, what: str = "r6", lib=None):
     if rc != 0:
         msg = (lib if lib is not None else load()).r6_last_error().decode(errors="replace")
         raise R6Error(f"{what} failed (rc={rc}): {msg}")
+
+
+def tune(key: str, value: float, lib=None):
+    """Sets a launch-shape knob of ``r6_step`` (include/r6dof.h ``r6_tune``); results never depend on it."""
+    lib = lib if lib is not None else load()
+    check(lib.r6_tune(key.encode(), float(value)), "r6_tune", lib)

@@ -871,4 +871,36 @@ __device__ __forceinline__ void sample_ic(const R6Params& p, uint64_t seed, uint
     ic[9] *= inv;
 }
 
+// The same draw for ONE env, computed by a whole wave: the four Philox blocks of sample_ic() run side by side in the lanes
+// (block = lane & 3) and the sixteen words come back through v_readlane, so every lane leaves with the same 14 values.
+// Where one lane of a wave needs a fresh initial condition (r6_step_k: ~1 finished env per wave and step) this is one
+// Philox pass instead of four with 63 lanes masked off.  `gid` / `step_index` are wave-uniform.  Bit for bit sample_ic().
+__device__ __forceinline__ void sample_ic_wave(const R6Params& p, uint64_t seed, uint64_t gid, uint64_t step_index, int lane,
+                                               float (&ic)[R6_STATE_DIM]) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t blk = (uint32_t)lane & 3u;
+    const U4 r = philox4x32_10(U4{(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step_index,
+                                  ((uint32_t)(step_index >> 32) & 0x3FFFFFFFu) | (blk << 30)},
+                               k0, k1);
+    uint32_t w[16];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        w[4 * b + 0] = (uint32_t)__builtin_amdgcn_readlane((int)r.x, b);
+        w[4 * b + 1] = (uint32_t)__builtin_amdgcn_readlane((int)r.y, b);
+        w[4 * b + 2] = (uint32_t)__builtin_amdgcn_readlane((int)r.z, b);
+        w[4 * b + 3] = (uint32_t)__builtin_amdgcn_readlane((int)r.w, b);
+    }
+#pragma unroll
+    for (int j = 0; j < R6_STATE_DIM; ++j) {
+        const float u = (float)(w[j] >> 8) * 5.9604644775390625e-08f;  // 2^-24
+        ic[j] = fmaf(u, p.ic_range[j], p.ic_lo[j]);
+    }
+    const float n2 = fmaf(ic[6], ic[6], fmaf(ic[7], ic[7], fmaf(ic[8], ic[8], ic[9] * ic[9])));
+    const float inv = 1.0f / sqrtf(n2);
+    ic[6] *= inv;
+    ic[7] *= inv;
+    ic[8] *= inv;
+    ic[9] *= inv;
+}
+
 }  // namespace r6

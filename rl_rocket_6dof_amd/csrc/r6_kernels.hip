@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
@@ -56,6 +57,9 @@ constexpr int kWaves = kBlock / 64;
 #endif
 #ifndef R6_RESET_QUEUE
 #define R6_RESET_QUEUE 2048
+#endif
+#ifndef R6_EARLY_LOAD
+#define R6_EARLY_LOAD 1         // A/B switch (RK4 / RK45 instances): rotated tile loop, first tile requested before the set-up barrier
 #endif
 constexpr int kResetQueueCap = R6_RESET_QUEUE;
 
@@ -135,6 +139,30 @@ __device__ __forceinline__ void reset_env_global(const R6Params& p, const R6Buff
     if (b.ep_return) b.ep_return[i] = 0.0f;
 }
 
+// Episode statistics of a workgroup: exact integer / fixed-point sums in LDS (native 64-bit integer atomics), so that the
+// totals depend neither on the order in which lanes and waves arrive nor on the launch shape: counts and lengths as integers,
+// the episode return in units of 2^-16 (|return| < 32768; its square in units of 2^-16 too, from the quantised return).
+// A workgroup's sums go to its own float64 row of R6Buffers.stats (exact: integers * 2^-16 far below 2^53).
+typedef unsigned long long stat_t;
+constexpr float kStatScale = 65536.0f;
+__device__ __forceinline__ void stats_add_episode(stat_t* blk, float ep_ret, uint32_t ep_step, bool ground, bool bnd, bool truncated, bool landed) {
+    const float clamped = fminf(fmaxf(ep_ret, -32767.0f), 32767.0f);
+    const int q = __float2int_rn(clamped * kStatScale);
+    const long long q2 = ((long long)q * (long long)q) >> 16;
+    atomicAdd(&blk[R6_STAT_EPISODES], (stat_t)1);
+    atomicAdd(&blk[R6_STAT_RETURN], (stat_t)(long long)q);
+    atomicAdd(&blk[R6_STAT_RETURN_SQ], (stat_t)q2);
+    atomicAdd(&blk[R6_STAT_LENGTH], (stat_t)ep_step);
+    if (ground) atomicAdd(&blk[R6_STAT_GROUND], (stat_t)1);
+    if (bnd) atomicAdd(&blk[R6_STAT_BOUNDS], (stat_t)1);
+    if (truncated) atomicAdd(&blk[R6_STAT_TRUNCATED], (stat_t)1);
+    if (landed) atomicAdd(&blk[R6_STAT_LANDED], (stat_t)1);
+}
+__device__ __forceinline__ double stats_value(const stat_t* blk, int j) {
+    const double v = (double)(long long)blk[j];
+    return (j == R6_STAT_RETURN || j == R6_STAT_RETURN_SQ) ? v * (1.0 / 65536.0) : v;
+}
+
 // Inputs of one 64-env tile, one lane = one env.
 struct TileIn {
     float y[kDyn];
@@ -205,7 +233,8 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset,
-                                                      const uint32_t even_share_q16, const uint32_t sweep) {
+                                                      const uint32_t even_share_q16, const uint32_t sweep,
+                                                      const uint32_t main_blocks, const uint32_t tail_tiles) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
     // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
@@ -216,7 +245,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     __shared__ int rq[kResetQueueCap];
     __shared__ int rq_count;
     __shared__ int wg_next;
-    __shared__ float blk_stats[R6_NUM_STATS];
+    __shared__ stat_t blk_stats[R6_NUM_STATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,15 +259,28 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     // equal shares the even XCDs are done at 0.8 of the launch.  even_share_q16 > 0 (persistent grids only): the tile
     // range is cut into an even-XCD pool of n_tiles * share / 65536 tiles and an odd-XCD pool with the rest, each
     // walked round-robin by the waves of its own workgroups.  0: one pool for everybody.
-    int64_t nw = (int64_t)gridDim.x * kWaves;
+    //
+    // Tail pool (round 3).  tail_tiles > 0: the launch has more workgroups than the chip holds.  The first `main_blocks`
+    // (= the resident capacity) walk the first n_tiles - tail_tiles tiles as above; the workgroups behind them are
+    // dispatched by the hardware as resident ones exit -- on whichever CU is done first -- and take the last `tail_tiles`
+    // tiles, one tile list entry per wave and round.  The static lists cannot know which SIMD will be late in a given
+    // launch (no correlation between launches); the dispatcher does, and a late workgroup's load latency hides behind the
+    // four workgroups still computing on its CU.
+    const int64_t n_main = n_tiles - (int64_t)tail_tiles;
+    int64_t nw = (int64_t)main_blocks * kWaves;
     int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
-    int64_t pool_base = 0, pool_tiles = n_tiles;
-    if (even_share_q16 != 0u) {
-        const int64_t n_even = (n_tiles * (int64_t)even_share_q16) >> 16;
+    int64_t pool_base = 0, pool_tiles = n_main;
+    if (blockIdx.x >= main_blocks) {
+        pool_base = n_main;
+        pool_tiles = tail_tiles;
+        nw = (int64_t)(gridDim.x - main_blocks) * kWaves;
+        t_first = (int64_t)(blockIdx.x - main_blocks) * kWaves + wave;
+    } else if (even_share_q16 != 0u) {
+        const int64_t n_even = (n_main * (int64_t)even_share_q16) >> 16;
         const bool odd = (blockIdx.x & 1u) != 0u;
         pool_base = odd ? n_even : 0;
-        pool_tiles = odd ? n_tiles - n_even : n_even;
-        nw = (int64_t)(gridDim.x >> 1) * kWaves;
+        pool_tiles = odd ? n_main - n_even : n_even;
+        nw = (int64_t)(main_blocks >> 1) * kWaves;
         t_first = (int64_t)(blockIdx.x >> 1) * kWaves + wave;
     }
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
@@ -247,16 +289,24 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
 #if defined(R6_PHASE_TIMING) || defined(R6_TRACE)   // dev builds: 100 MHz wall-clock stamps instead of the episode statistics
     const uint64_t pt0 = wall_clock64();
 #endif
+#ifdef R6_CLOCK_PROBE   // dev build (scripts/clock_probe.py): shader cycles against the 100 MHz wall clock over a workgroup's life
+    const uint64_t cp_r0 = wall_clock64();
+    const uint64_t cp_s0 = __builtin_amdgcn_s_memtime();
+#endif
     if (tid == 0) {
         rq_count = 0;
         wg_next = kWaves;   // list entries 0..kWaves-1 are the waves' fixed first tiles
     }
-    if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
+    if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
     if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
         const kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
         lds_inv_norm[tid] = ((const __attribute__((address_space(4))) float*)(k + offsetof(R6Params, inv_norm)))[tid];
     }
-    __syncthreads();
+    // kEarly (RK4 / RK45 instances): the barrier that publishes the LDS set-up above comes AFTER the wave has requested its
+    // first tile (below) -- nothing of the set-up is needed before a tile's reward phase, and the per-lane kernarg read is a
+    // memory round trip that the first loads of the launch need not queue behind.
+    constexpr bool kEarly = (R6_EARLY_LOAD != 0) && (INTEG != R6_EULER);
+    if constexpr (!kEarly) __syncthreads();
 
     // One 64-env tile.  FULL = all 64 lanes are live (every tile but possibly the last one).
     auto process_tile = [&](const int64_t e0, const TileIn& in, auto full_c) __attribute__((always_inline)) {
@@ -382,14 +432,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         if (live && done) {
             const R6Buffers bb = load_buffers();
             if (bb.stats) {
-                atomicAdd(&blk_stats[R6_STAT_EPISODES], 1.0f);
-                atomicAdd(&blk_stats[R6_STAT_RETURN], ep_ret);
-                atomicAdd(&blk_stats[R6_STAT_RETURN_SQ], ep_ret * ep_ret);
-                atomicAdd(&blk_stats[R6_STAT_LENGTH], (float)ep_step);
-                if (status == 1) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
-                if (bnd) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
-                if (truncated) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
-                if (landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
+                stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
             }
             if (p.auto_reset) {
                 const int64_t i = e0 + ln;
@@ -496,12 +539,57 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     };
     const int n_pos = kWgDyn ? n_wg : n_my;
     int wg_jn = -1;
+    if constexpr (kEarly) {
+        // Rotated tile loop: a tile's inputs are requested at the bottom of the previous iteration, the first tile's
+        // before the set-up barrier.
+        auto tile_at = [&](int pos) __attribute__((always_inline)) -> int64_t {
+            const int64_t ts = pool_base + list_tile(pos);
+            return (sweep & 2u) ? (n_tiles - 1 - ts) : ts;
+        };
+        TileIn cur;
+        int64_t t = 0;
+        if (sweep & 8u) {   // A/B: the workgroups that arrive third, fourth, fifth on a CU ask for their first tile later
+            const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;   // HW_ID.wave_id: the wave's slot on its SIMD
+            if (slot >= 2u) __builtin_amdgcn_s_sleep(24);
+            if (slot >= 3u) __builtin_amdgcn_s_sleep(12);
+            if (slot >= 4u) __builtin_amdgcn_s_sleep(12);
+        }
+        if (n_pos > 0) {
+            t = tile_at(0);
+            if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
+            else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int pos = 0; pos < n_pos;) {
+            if (sweep & 4u) {   // A/B: no priority ladder (oldest wave first)
+            } else if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
+            else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
+            else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            ++tile_no;
+            bool overflow;
+            if (t < n_full) overflow = process_tile(t * 64, cur, std::true_type{});
+            else overflow = process_tile(t * 64, cur, std::false_type{});
+            if (__builtin_expect(__any(overflow), 0)) {
+                __builtin_amdgcn_s_waitcnt(0);
+                if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
+            }
+            ++pos;
+            if (pos < n_pos) {
+                t = tile_at(pos);
+                if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
+                else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int pos = kWgDyn ? wave : 0; pos < n_pos;) {
         const int64_t tp = list_tile(pos);
         const int64_t ts = pool_base + tp;
         const int64_t t = (sweep & 2u) ? (n_tiles - 1 - ts) : ts;
-        if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
+        if (sweep & 4u) {   // A/B: no priority ladder (oldest wave first)
+        } else if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
         else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
         else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
@@ -579,6 +667,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
             ++pos;
         }
     }
+    }   // !kEarly
     __builtin_amdgcn_s_setprio(0);
 
 #ifdef R6_PHASE_TIMING
@@ -596,8 +685,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     const int n_queued = rq_count;
     if (n_queued > 0) {
         const R6Buffers bb = load_buffers();
-#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE)
-        if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += (double)blk_stats[tid];
+#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE) && !defined(R6_CLOCK_PROBE)
+        if (bb.stats && tid < R6_NUM_STATS) bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
 #endif
 
         // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
@@ -607,11 +696,23 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
             reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
     } else if (!p.auto_reset) {
         const R6Buffers bb = load_buffers();
-#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE)
-        if (bb.stats && tid < R6_NUM_STATS && blk_stats[0] > 0.0f)
-            bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += (double)blk_stats[tid];
+#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE) && !defined(R6_CLOCK_PROBE)
+        if (bb.stats && tid < R6_NUM_STATS && blk_stats[0] != 0ull)
+            bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
 #endif
     }
+#ifdef R6_CLOCK_PROBE
+    if (b.stats && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint64_t cp_s1 = __builtin_amdgcn_s_memtime();
+        const uint64_t cp_r1 = wall_clock64();
+        double* o = b.stats + (int64_t)blockIdx.x * R6_NUM_STATS;
+        o[0] = (double)(cp_s1 - cp_s0);
+        o[1] = (double)(cp_r1 - cp_r0);
+        o[2] = (double)(uint32_t)cp_r0;
+        o[3] = (double)(uint32_t)cp_r1;
+    }
+#endif
 #ifdef R6_PHASE_TIMING
     if (b.stats && (tid & 63) == 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -649,7 +750,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                                                                                const uint64_t env_offset) {
     __shared__ __attribute__((aligned(16))) float tiles[kWaves][64 * OD];
     __shared__ float lds_inv_norm[R6_STATE_DIM];
-    __shared__ float blk_stats[R6_NUM_STATS];
+    __shared__ stat_t blk_stats[R6_NUM_STATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -662,8 +763,18 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
     const int K = sk.k;
     const bool last_only = (sk.flags & R6_K_LAST_ONLY) != 0;
 
-    if (tid < R6_NUM_STATS) blk_stats[tid] = 0.0f;
+#ifdef R6_TRACE_K   // dev build (scripts/stepk_trace.py): per-wave 100 MHz stamps, written to the rows of `stats`
+    const uint64_t tk0 = wall_clock64();
+    uint64_t tk1 = 0, tk2 = 0, tk3 = 0;
+    int tk_resets = 0;
+    uint64_t tk_reg[4] = {0, 0, 0, 0}, tk_reg_d[4] = {0, 0, 0, 0};   // shader cycles per region: dynamics, reward, outputs + episode end, obs stores; all steps / steps with an episode end
+#define TKSTAMP(v) __builtin_amdgcn_s_waitcnt(0xc07f); const uint64_t v = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xc07f)
+#else
+#define TKSTAMP(v)
+#endif
+    if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
     if (tid < R6_STATE_DIM) lds_inv_norm[tid] = p.inv_norm[tid];
+    const uint64_t step_base = b.step_base ? *b.step_base : (uint64_t)0;   // constant during the launch: read once (a scalar load)
     __syncthreads();
 
 #pragma unroll 1
@@ -673,6 +784,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
         const bool live = lane < rem;
         const bool full = rem >= 64;
         const int64_t i = e0 + lane;   // this lane's env (valid when live)
+        const int lane_ld = live ? lane : 0;   // lane whose action a padding lane may read
 
         // ---- state of the tile: read once ------------------------------------------------------------------
         float y[kDyn], mass = 4.0e4f, m0 = 4.0e4f, v0 = 0.0f, ep_ret = 0.0f;
@@ -701,20 +813,37 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
             a1 = act[3 * lane + 1];
             a2 = act[3 * lane + 2];
         }
+        // Everything the K loop carries in registers is made "arrived" HERE (the empty asm statements read the registers, so
+        // the compiler's s_waitcnt for the loads above lands in front of the loop).  gfx9 counts loads and stores in ONE
+        // in-order counter (vmcnt): left to itself the compiler waits for the pre-loop loads at their first use inside the
+        // loop, with the only count that is safe on the entry edge -- vmcnt(0) -- and that wait then runs in EVERY iteration,
+        // right behind the request for the next step's action: the prefetch was waited for on the spot, together with all
+        // stores of the previous step (round 2: 42 % of the wave's cycles in s_waitcnt, profiles/r3_pmc_stepk.json).
+#pragma unroll
+        for (int j = 0; j < kDyn; ++j) asm volatile("" : "+v"(y[j]));
+        asm volatile("" : "+v"(mass), "+v"(m0), "+v"(v0), "+v"(ep_ret), "+v"(ep_step));
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+#ifdef R6_TRACE_K
+        tk1 = wall_clock64();
+#endif
 
 #pragma unroll 1
         for (int k = 0; k < K; ++k) {
-            // next step's action is requested before this step is computed
-            float n0 = 0.0f, n1 = 0.0f, n2 = -1.0f;
-            if (live && k + 1 < K) {
-                const gptr<const float> act = uniform_ptr(b.action + ((int64_t)(k + 1) * sk.action_stride + e0 * R6_ACTION_DIM));
-                n0 = act[3 * lane + 0];
-                n1 = act[3 * lane + 1];
-                n2 = act[3 * lane + 2];
+            // next step's action is requested before this step is computed.  The request is unconditional -- a load inside
+            // a lane-masked block ends in a register merge that waits for it on the spot -- so the last step re-reads its own
+            // action and the padding lanes of a partial tile read lane 0's (valid addresses, values never used).
+            float n0, n1, n2;
+            {
+                const int kn = (k + 1 < K) ? k + 1 : k;
+                const gptr<const float> act = uniform_ptr(b.action + ((int64_t)kn * sk.action_stride + e0 * R6_ACTION_DIM));
+                n0 = act[3 * lane_ld + 0];
+                n1 = act[3 * lane_ld + 1];
+                n2 = act[3 * lane_ld + 2];
             }
             const bool emit = !last_only || k + 1 == K;   // wave-uniform: this step's outputs leave the chip
 
             // ---- dynamics (sim:69-143) ---------------------------------------------------------------------
+            TKSTAMP(ts0);
             const Control c = make_control_normalised(p, a0, a1, a2);
             const Inertia J = make_inertia(m0);
             int nfev = 0, status;
@@ -724,6 +853,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                 status = integrate<INTEG, true, ONE>(y, mass, c, J, p.dt, p.n_substeps);
                 nfev = (INTEG == R6_RK4 ? 4 : 1) * (ONE ? 1 : p.n_substeps);
             }
+            TKSTAMP(ts1);
 
             // ---- termination, reward, fused wrappers: the same sequence as step_kernel ---------------------------
             const R6Params pr = load_params();   // (kept resident in SGPRs across the K loop instead: 3.61 -> 3.77 us per step at N = 65 536)
@@ -748,6 +878,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                 done = true;
             }
 
+            TKSTAMP(ts2);
+            // The next step's action has arrived by now (a whole step of arithmetic after its request), and so have the
+            // previous step's stores: the vmcnt(0) the compiler needs before this read costs nothing HERE, in front of this
+            // step's stores -- at the top of the next iteration it would wait for them (see above).  The "memory" clobber
+            // keeps the stores below from being scheduled in front of it.
+            asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2) : : "memory");
+
             // ---- per-step outputs -----------------------------------------------------------------------------------
             if (live && emit) {
                 uniform_ptr(b.reward + ((int64_t)k * sk.reward_stride + e0))[lane] = rew;
@@ -765,16 +902,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
             if (OD == 14) tile[lane * OD + (OD - 1)] = mass * lds_inv_norm[13];
 
             // ---- finished episodes: terminal outputs, statistics, and Rocket6DOF.reset (env:180-199) in the lane -----
+#ifdef R6_TRACE_K
+            if (__any(live && done)) ++tk_resets;
+#endif
+            TKSTAMP(ts2b);
             if (live && done) {
                 if (b.stats) {
-                    atomicAdd(&blk_stats[R6_STAT_EPISODES], 1.0f);
-                    atomicAdd(&blk_stats[R6_STAT_RETURN], ep_ret);
-                    atomicAdd(&blk_stats[R6_STAT_RETURN_SQ], ep_ret * ep_ret);
-                    atomicAdd(&blk_stats[R6_STAT_LENGTH], (float)ep_step);
-                    if (status == 1) atomicAdd(&blk_stats[R6_STAT_GROUND], 1.0f);
-                    if (bnd) atomicAdd(&blk_stats[R6_STAT_BOUNDS], 1.0f);
-                    if (truncated) atomicAdd(&blk_stats[R6_STAT_TRUNCATED], 1.0f);
-                    if (landed) atomicAdd(&blk_stats[R6_STAT_LANDED], 1.0f);
+                    stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
                 }
                 if (p.auto_reset) {
                     if (emit) {
@@ -786,21 +920,38 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                         if (b.fin_return) b.fin_return[(int64_t)k * sk.fin_stride + i] = ep_ret;
                         if (b.fin_length) b.fin_length[(int64_t)k * sk.fin_stride + i] = ep_step;
                     }
-                    float ic[R6_STATE_DIM];
-                    sample_ic(load_params(), seed, env_offset + (uint64_t)i,
-                              step_index + (uint64_t)k + (b.step_base ? *b.step_base : (uint64_t)0), ic);
+                }
+            }
+            TKSTAMP(ts2c);
+            // Rocket6DOF.reset (env:180-199) for the envs that finished in this step, one env at a time with the whole wave
+            // working on its draw (sample_ic_wave): typically ONE lane of the 64 needs it, and the in-lane form -- every
+            // lane its own four Philox blocks, 63 of them masked off -- cost 1.4 us per reset at one wave per SIMD and made
+            // a launch as long as its unluckiest wave (per-wave stamps, scripts/stepk_trace.py).  Same values, bit for bit.
+            if (p.auto_reset) {
+                uint64_t fin = __ballot(live && done);
+                if (fin != 0ull) {
+                    const R6Params pp = load_params();
+                    do {
+                        const int j = __builtin_ctzll(fin);
+                        fin &= fin - 1ull;
+                        float ic[R6_STATE_DIM];
+                        sample_ic_wave(pp, seed, env_offset + (uint64_t)(e0 + j), step_index + (uint64_t)k + step_base, lane, ic);
+                        if (lane == j) {
 #pragma unroll
-                    for (int j = 0; j < kDyn; ++j) y[j] = ic[j];
-                    mass = m0 = ic[13];
-                    v0 = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
-                    ep_step = 0u;
-                    ep_ret = 0.0f;
+                            for (int q = 0; q < kDyn; ++q) y[q] = ic[q];
+                            mass = m0 = ic[13];
+                            v0 = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
+                            ep_step = 0u;
+                            ep_ret = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < OD; ++j) tile[lane * OD + j] = ic[j] * lds_inv_norm[j];   // the fresh episode's first observation
+                            for (int q = 0; q < OD; ++q) tile[lane * OD + q] = ic[q] * lds_inv_norm[q];   // the fresh episode's first observation
+                        }
+                    } while (fin != 0ull);
                 }
             }
 
             // ---- LDS tile -> contiguous 16 B-per-lane stores of this step's (64, OD) observation block -----------------
+            TKSTAMP(ts3);
             wave_lds_sync();
             if (emit) {
                 const gptr<float> dst = uniform_ptr(b.obs + ((int64_t)k * sk.obs_stride + e0 * OD));
@@ -816,11 +967,25 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                 }
             }
             wave_lds_sync();
+#ifdef R6_TRACE_K
+            {
+                TKSTAMP(ts4);
+                const bool any_done = __any(live && done);
+                const uint64_t d[4] = {ts2b - ts2, ts2c - ts2b, ts3 - ts2c, ts4 - ts3};   // per-step outputs + obs tile | terminal outputs | reset | obs stores
+                for (int q = 0; q < 4; ++q) {
+                    tk_reg[q] += d[q];
+                    if (any_done) tk_reg_d[q] += d[q];
+                }
+            }
+#endif
             a0 = n0;
             a1 = n1;
             a2 = n2;
         }
 
+#ifdef R6_TRACE_K
+        tk2 = wall_clock64();
+#endif
         // ---- state of the tile: written once -----------------------------------------------------------------
         if (live) {
             float* row = b.state + e0;
@@ -839,9 +1004,29 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
         }
     }
 
+#ifdef R6_TRACE_K
+    __builtin_amdgcn_s_waitcnt(0);
+    tk3 = wall_clock64();
+    if (b.stats && lane == 0) {
+        double* o = b.stats + ((int64_t)blockIdx.x * kWaves + wave) * R6_NUM_STATS;   // needs grid * 4 <= R6_MAX_BLOCKS rows
+        o[0] = (double)(uint32_t)tk0;
+        o[1] = (double)(uint32_t)tk1;
+        o[2] = (double)(uint32_t)tk2;
+        o[3] = (double)(uint32_t)tk3;
+        o[4] = (double)tk_resets;
+        o[5] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        o[6] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+        double* o2 = b.stats + ((int64_t)gridDim.x * kWaves + (int64_t)blockIdx.x * kWaves + wave) * R6_NUM_STATS;
+        for (int q = 0; q < 4; ++q) {
+            o2[q] = (double)tk_reg[q];
+            o2[4 + q] = (double)tk_reg_d[q];
+        }
+    }
+    return;
+#endif
     __syncthreads();
-    if (b.stats && tid < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] > 0.0f)
-        b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += (double)blk_stats[tid];
+    if (b.stats && tid < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] != 0ull)
+        b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -991,19 +1176,114 @@ bool device_has_eight_xcds() {
 #ifndef R6_EVEN_SHARE_DEFAULT
 #define R6_EVEN_SHARE_DEFAULT -1.0   // < 0: per-integrator default (RK4 0.54, Euler 0.56)
 #endif
+#ifndef R6_TAIL_FRAC_DEFAULT
+#define R6_TAIL_FRAC_DEFAULT 0.0
+#endif
+#ifndef R6_SPLIT_DEFAULT
+#define R6_SPLIT_DEFAULT 0
+#endif
+
+// ---- launch shape of r6_step: tuning state (defaults from measurements; R6_* environment variables and r6_tune()
+//      override them -- results never depend on any of it, only which wave computes which tile) ----------------------------
+struct StepTune {
+    std::atomic<double> even_share{R6_EVEN_SHARE_DEFAULT};   // < 0: per-integrator default
+    std::atomic<double> tail_frac{R6_TAIL_FRAC_DEFAULT};     // share of the tiles in the tail pool (0 = none)
+    std::atomic<int> tail_tpw{1};                            // tiles per wave of a tail workgroup
+    std::atomic<int> split{R6_SPLIT_DEFAULT};                // 0: one launch; 1: two launches fork/joined on a library-owned stream
+    std::atomic<double> split_frac{0.5};                     // share of the envs in the first launch
+    std::atomic<int> split_min_tiles{12288};                 // shards below this many tiles are never split
+    std::atomic<int> grid_blocks{0};                         // > 0: pins the persistent grid (R6_GRID_BLOCKS)
+    std::atomic<int> sweep{R6_SWEEP_DEFAULT};
+    std::atomic<int> sweep_flags{0};                         // A/B bits passed to the kernel: 4 = no priority ladder, 8 = staggered first loads
+    StepTune() {
+        if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) even_share = std::atof(e);
+        if (const char* e = std::getenv("R6_TAIL_FRAC")) tail_frac = std::atof(e);
+        if (const char* e = std::getenv("R6_TAIL_TPW")) tail_tpw = std::atoi(e);
+        if (const char* e = std::getenv("R6_SPLIT")) split = std::atoi(e);
+        if (const char* e = std::getenv("R6_SPLIT_FRAC")) split_frac = std::atof(e);
+        if (const char* e = std::getenv("R6_GRID_BLOCKS")) grid_blocks = std::atoi(e);
+        if (const char* e = std::getenv("R6_SWEEP")) sweep = std::atoi(e);
+    }
+};
+StepTune& tune() {
+    static StepTune t;
+    return t;
+}
+
 uint32_t even_xcd_share_q16(int integrator) {
-    static const double forced = [] {
-        double f = R6_EVEN_SHARE_DEFAULT;
-        if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) f = std::atof(e);
-        return f;
-    }();
+    const double forced = tune().even_share.load(std::memory_order_relaxed);
     const double f = forced >= 0.0 ? forced : (integrator == R6_EULER ? 0.56 : 0.54);
     if (!(f > 0.0) || f == 0.5 || f >= 1.0) return 0u;
     return (uint32_t)(f * 65536.0 + 0.5);
 }
 
+// Fork/join resources of one (device, caller stream) pair: a library-owned side stream and two events.  Created on first
+// use outside stream capture (resource creation is not allowed while a stream captures); a caller stream without an entry
+// simply gets the single-launch form.
+struct ForkJoin {
+    int dev = -1;
+    hipStream_t caller = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool used = false;
+};
+ForkJoin* fork_join_for(hipStream_t caller) {
+    static std::mutex mu;
+    static ForkJoin table[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : table)
+        if (e.used && e.dev == dev && e.caller == caller) return &e;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    for (auto& e : table) {
+        if (e.used) continue;
+        if (hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        e.dev = dev;
+        e.caller = caller;
+        e.used = true;
+        return &e;
+    }
+    return nullptr;
+}
+
+// The envs [e0, e0 + cnt) of a shard as a shard of their own (e0 a multiple of 64): every pointer advanced, the
+// statistics rows of its workgroups start at `block_base`.  The reset RNG is keyed by the global env index: the caller
+// adds e0 to env_offset.
+R6Buffers sub_shard(const R6Buffers& b, int64_t e0, int64_t cnt, int od, int64_t block_base) {
+    R6Buffers v = b;
+    v.n = cnt;
+    v.state = b.state + e0;
+    v.epconst = b.epconst + e0;
+    v.action = b.action + e0 * R6_ACTION_DIM;
+    v.obs = b.obs + e0 * od;
+    v.reward = b.reward + e0;
+    v.done = b.done + e0;
+    if (b.flags) v.flags = b.flags + e0;
+    if (b.terms) v.terms = b.terms + e0;
+    if (b.final_obs) v.final_obs = b.final_obs + e0 * od;
+    if (b.ep_step) v.ep_step = b.ep_step + e0;
+    if (b.ep_return) v.ep_return = b.ep_return + e0;
+    if (b.fin_return) v.fin_return = b.fin_return + e0;
+    if (b.fin_length) v.fin_length = b.fin_length + e0;
+    if (b.nfev) v.nfev = b.nfev + e0;
+    if (b.stats) v.stats = b.stats + block_base * R6_NUM_STATS;
+    return v;
+}
+
+// One launch of the step kernel over a whole shard; returns the number of workgroups (= statistics rows) it used.
 template <int INTEG, int SHAPING, int OD>
-void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
+int64_t launch_step_one(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s,
+                        int64_t max_blocks, bool allow_tail) {
     auto kernel = r6::step_kernel<INTEG, SHAPING, OD>;
     if constexpr (INTEG != R6_RK45) {
         // ONE: n_substeps == 1 (the reference's configuration) gets the straight-line integrator instance;
@@ -1015,19 +1295,37 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);   // both forms share launch bounds and occupancy
     const int64_t n_tiles = (b.n + 63) / 64;
     int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
-    const int cap = resident_blocks(kernel, slot);
+    int64_t cap = resident_blocks(kernel, slot);
+    const int pinned_blocks = tune().grid_blocks.load(std::memory_order_relaxed);
+    if (pinned_blocks > 0) cap = pinned_blocks;
+    if (cap > max_blocks) cap = max_blocks;
     if (blocks > cap) {
         // Up to ~3 M envs the grid is the resident capacity (persistent waves, ~3-10 tiles each).  Beyond that the
         // hardware dispatcher balances better than a fixed tile list per wave: two tiles per wave, as many
         // workgroups as the per-workgroup statistics rows allow (N = 2^22: 4.6 -> 5.1 TB/s algorithmic, 2^23:
         // 3.8 -> 4.6, 2^24: 3.8 -> 5.1; at 2^20 / 2^21 the resident grid is 4-13 % faster).
-        static const bool pinned = std::getenv("R6_GRID_BLOCKS") != nullptr;
         const int64_t big = n_tiles / (2 * r6::kWaves);
-        blocks = (!pinned && n_tiles >= 49152 && big > cap) ? (big < R6_MAX_BLOCKS ? big : R6_MAX_BLOCKS) : cap;
+        blocks = (pinned_blocks <= 0 && n_tiles >= 49152 && big > cap) ? (big < max_blocks ? big : max_blocks) : cap;
+    }
+    const bool persistent = blocks == cap && n_tiles >= 2 * blocks * r6::kWaves;
+    // Tail pool (see step_kernel): only on the persistent grid
+    uint32_t main_blocks = (uint32_t)blocks, tail_tiles = 0;
+    if (allow_tail && persistent && INTEG != R6_RK45) {
+        const double tf = tune().tail_frac.load(std::memory_order_relaxed);
+        const int tpw = tune().tail_tpw.load(std::memory_order_relaxed);
+        if (tf > 0.0 && tf < 0.5 && tpw >= 1) {
+            const int64_t per_block = (int64_t)r6::kWaves * tpw;
+            int64_t tb = (int64_t)((double)n_tiles * tf / (double)per_block + 0.5);
+            if (blocks + tb > max_blocks) tb = max_blocks - blocks;
+            if (tb > 0) {
+                tail_tiles = (uint32_t)(tb * per_block);
+                blocks += tb;
+            }
+        }
     }
     // XCD-aware split (see step_kernel): only for the persistent grid, where every wave walks several tiles
     uint32_t even_share = 0;
-    if (blocks == cap && (blocks % 8) == 0 && n_tiles >= 2 * blocks * r6::kWaves && device_has_eight_xcds()) even_share = even_xcd_share_q16(INTEG);
+    if (persistent && (main_blocks % 8) == 0 && device_has_eight_xcds()) even_share = even_xcd_share_q16(INTEG);
     // Order of the tiles on odd steps (see step_kernel).  Measured in one process at N = 2^20 / 2^21 / 2^22 (us per step;
     // as even steps | every wave's list backwards | whole range mirrored): RK4 38.0 | 39.4 | 38.8, 85.2 | 90.8 | 90.1,
     // 154 | 159 | 162 (the last size runs the dispatcher-balanced grid, where only "mirrored" exists: its three numbers are
@@ -1035,11 +1333,45 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     // So: the RK4 / RK45 instances keep one order on the resident grid, the Euler instances walk their lists backwards,
     // and the dispatcher-balanced grid mirrors the range (N = 2^23: 328 -> 291 us with the streaming stores, round 1).
     // R6_SWEEP=0|1|2 overrides the resident-grid choice.
-    static const int sweep_env = [] { const char* e = std::getenv("R6_SWEEP"); return e ? std::atoi(e) : R6_SWEEP_DEFAULT; }();
+    const int sweep_env = tune().sweep.load(std::memory_order_relaxed);
     const int sweep_mode = sweep_env >= 0 ? sweep_env : (INTEG == R6_EULER ? 1 : 0);
     uint32_t sweep = 0;
-    if (step & 1) sweep = (blocks > cap || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep);
+    if (step & 1) sweep = (main_blocks > cap || (blocks > cap && tail_tiles == 0) || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
+    sweep |= (uint32_t)tune().sweep_flags.load(std::memory_order_relaxed) & 12u;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep, main_blocks, tail_tiles);
+    return blocks;
+}
+
+// r6_step for one shard: one launch, or -- large shards, split enabled -- the shard's two halves as two launches, the
+// first on the caller's stream and the second on a library-owned stream forked from and joined back to it with events
+// (capturable into a HIP graph like any fork/join).  Launches of ONE stream serialise: the ~4 us in which a launch only
+// waits for its first loads and the ~5 us in which its SIMDs run dry one after the other cannot overlap with
+// anything.  The two halves are independent (tiles never interact), so the second half's ramp runs under the first
+// half's tail.  Results are bit-identical to the single launch: which launch computes a tile never matters, and the two
+// grids use disjoint statistics rows.
+template <int INTEG, int SHAPING, int OD>
+void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
+    const int64_t n_tiles = (b.n + 63) / 64;
+    const int split = tune().split.load(std::memory_order_relaxed);
+    if (split != 0 && INTEG != R6_RK45 && n_tiles >= tune().split_min_tiles.load(std::memory_order_relaxed) && b.n < R6_NT_MIN_ENVS) {
+        if (ForkJoin* fj = fork_join_for(s)) {
+            double f = tune().split_frac.load(std::memory_order_relaxed);
+            if (!(f > 0.05 && f < 0.95)) f = 0.5;
+            const int64_t t0 = (int64_t)((double)n_tiles * f + 0.5);
+            const int64_t e0 = t0 * 64;
+            const R6Buffers a = sub_shard(b, 0, e0, OD, 0);
+            if (hipEventRecord(fj->fork, s) == hipSuccess && hipStreamWaitEvent(fj->side, fj->fork, 0) == hipSuccess) {
+                const int64_t blocks_a = launch_step_one<INTEG, SHAPING, OD>(p, a, seed, step, off, s, R6_MAX_BLOCKS / 2, true);
+                const R6Buffers c = sub_shard(b, e0, b.n - e0, OD, blocks_a);
+                launch_step_one<INTEG, SHAPING, OD>(p, c, seed, step, off + (uint64_t)e0, fj->side, R6_MAX_BLOCKS - blocks_a, true);
+                (void)hipEventRecord(fj->join, fj->side);
+                (void)hipStreamWaitEvent(s, fj->join, 0);
+                return;
+            }
+            (void)hipGetLastError();
+        }
+    }
+    launch_step_one<INTEG, SHAPING, OD>(p, b, seed, step, off, s, R6_MAX_BLOCKS, true);
 }
 
 template <int INTEG, int SHAPING, int OD>
@@ -1084,6 +1416,22 @@ int r6_abi_version(void) { return R6_ABI_VERSION; }
 size_t r6_params_size(void) { return sizeof(R6Params); }
 size_t r6_buffers_size(void) { return sizeof(R6Buffers); }
 const char* r6_last_error(void) { return g_err; }
+
+int r6_tune(const char* key, double value) {
+    if (!key) return fail(R6_E_BADARG, "r6_tune: null key");
+    StepTune& t = tune();
+    if (!std::strcmp(key, "even_xcd_share")) t.even_share = value;
+    else if (!std::strcmp(key, "tail_frac")) t.tail_frac = value;
+    else if (!std::strcmp(key, "tail_tiles_per_wave")) t.tail_tpw = (int)value;
+    else if (!std::strcmp(key, "split")) t.split = (int)value;
+    else if (!std::strcmp(key, "split_frac")) t.split_frac = value;
+    else if (!std::strcmp(key, "split_min_tiles")) t.split_min_tiles = (int)value;
+    else if (!std::strcmp(key, "grid_blocks")) t.grid_blocks = (int)value;
+    else if (!std::strcmp(key, "sweep")) t.sweep = (int)value;
+    else if (!std::strcmp(key, "sweep_flags")) t.sweep_flags = (int)value;
+    else return fail(R6_E_BADARG, "r6_tune: unknown key");
+    return 0;
+}
 
 int r6_step(const R6Params* params, const R6Buffers* buf, uint64_t seed, uint64_t step_index, uint64_t env_offset,
             void* stream) {
