@@ -78,13 +78,103 @@ def cpu_baseline(seconds: float):
             if d:
                 env.reset()
     el = time.perf_counter() - t0
-    out = {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    out = {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
            "sample": f"{steps} random-action steps of one env (config.yaml, dt 0.1, adaptive RK45 + event + "
                      f"np.roots reward, reset on done) in {el:.1f} s on 1 of {os.cpu_count()} host cores"}
+    out["all_cores"] = cpu_baseline_all_cores(max(3.0, seconds / 2))
     c = cpu_baseline_c(max(2.0, seconds / 3))
     if c is not None:
         out["best_cpu"] = c
     return out
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: the scheduler affinity mask, cut by a cgroup CPU quota where one is set (a GPU
+    box hands a one-GPU job a share of its host cores, not all of os.cpu_count())."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+_WORKER = r"""
+import json, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from oracle import oracle_np as onp
+cfg, seconds, seed = json.loads(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
+env = onp.OracleEnv(cfg, integrator="adaptive", seed=seed)
+rng = np.random.RandomState(seed)
+env.reset()
+for _ in range(20):
+    _, _, d, _ = env.step(rng.uniform(-1, 1, 3).astype(np.float32))
+    if d:
+        env.reset()
+print("ready", flush=True)
+sys.stdin.readline()                      # all workers start their timed region together
+steps, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < seconds:
+    for _ in range(50):
+        _, _, d, _ = env.step(rng.uniform(-1, 1, 3).astype(np.float32))
+        steps += 1
+        if d:
+            env.reset()
+print(json.dumps({"steps": steps, "seconds": time.perf_counter() - t0}), flush=True)
+"""
+
+
+def cpu_baseline_all_cores(seconds: float, max_procs: int = 64):
+    """the same reference-equivalent loop as N independent processes, one per usable host core (the
+    reference is single-env, single-process Python: running one copy per core is how it scales on a host).  The workers are
+    fresh interpreters that import numpy / scipy and the oracle only -- they never touch the GPU."""
+    from rl_rocket_6dof_amd import default_env_config
+
+    cores = usable_cores()
+    procs_n = min(cores, max_procs)
+    cfg = json.dumps(default_env_config())
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = []
+    try:
+        for i in range(procs_n):
+            procs.append(subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, cfg, str(seconds), str(1000 + i)], env=env,
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("worker did not start")
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        res = [json.loads(p.stdout.readline()) for p in procs]
+        for p in procs:
+            p.wait(timeout=30)
+    except Exception as e:  # pragma: no cover
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return {"error": repr(e), "cores": procs_n}
+    total = sum(r["steps"] for r in res)
+    el = max(r["seconds"] for r in res)
+    return {"value": total / el, "unit": "env-steps/s", "cores": procs_n, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{procs_n} independent processes (one per usable core: {cores} usable of {os.cpu_count()} on the host), each the "
+                      f"single-env loop above for {seconds:.1f} s: {total} steps in all"}
 
 
 def cpu_baseline_c(seconds: float):
@@ -130,17 +220,22 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def git_commit() -> str:
-    """Commit of the sources: from git where .git exists, else the stamp the build left next to the library."""
-    try:
-        rev = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                             timeout=10).stdout.strip()
-        if rev:
-            return rev
-    except Exception:
-        pass
+def lib_commit() -> str:
+    """Source commit the HIP LIBRARY was built from: the stamp the build left next to libr6dof.so (it travels with the .so to
+    machines without .git).  bench.py / dist.py may be newer than it: see bench_py_sha16."""
     try:
         return open(os.path.join(ROOT, "rl_rocket_6dof_amd", "csrc", "BUILD_COMMIT")).read().strip() or "unknown"
+    except Exception:
+        return "unknown"
+
+
+def bench_py_sha16() -> str:
+    """First 16 hex digits of sha256(bench.py): identifies THIS file's version where there is no .git (the driver records the
+    same digest beside its run)."""
+    import hashlib
+
+    try:
+        return hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]
     except Exception:
         return "unknown"
 
@@ -208,7 +303,7 @@ def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: floa
                                f"{args.k} env step(s) per launch",
                    "envs_total": total, "integrator": args.integrator, "dt": dt, "variant": args.variant,
                    "steps_per_launch": args.k, "bytes_per_env_step": bytes_per, "parallelism": f"env-shard x{world}",
-                   "commit": git_commit()},
+                   "lib_commit": lib_commit(), "bench_py_sha16": bench_py_sha16()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_us": kernel_ms * 1e3 * max(args.k, 1), "kernel": kernel,
@@ -280,6 +375,40 @@ def side_measurement(torch, dev, cfg, *, n, integrator, dt, k, pool_count, burni
     return out
 
 
+def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) -> dict:
+    """The N > 1 record's second loop, itemised (rank-reduced with max over ranks):
+      first_gather_us   the very first all-gather of the process (communicator creation, buffer registration) timed alone,
+                        outside every other number;
+      then one UNTIMED pass with two gathers (warm), then, on the same env and the same number of steps,
+      wall without / with a gather every `gather_every` steps  ->  us_per_step_tracked_env, us_per_gather (the difference per
+      gather) and `value` (the loop with gathers, whole job)."""
+    ge = args.gather_every
+    gsteps = max(2 * ge, min(args.steps, 10 * ge) // ge * ge)
+    if args.k > 1:
+        gsteps = max(gsteps // args.k * args.k, args.k)
+    gathers = []     # per-rank tables stay on the device: the all-gather is stream-ordered, the loop never drains the GPU
+    do_gather = lambda: gathers.append(r6dist.gather_episode_stats_device(env_g.episode_stats_tensor()))
+    barrier()
+    t0 = time.perf_counter()
+    do_gather()
+    torch.cuda.synchronize(dev)
+    first_us = (time.perf_counter() - t0) * 1e6
+    timed_loop(env_g, pool, 2 * ge if args.k <= 1 else max(2 * ge // args.k * args.k, args.k), args.k, barrier, stream, torch,
+               every=(ge, do_gather))                                                        # warm: >= 2 gathers, untimed
+    wall_plain, _ = timed_loop(env_g, pool, gsteps, args.k, barrier, stream, torch)
+    n_before = len(gathers)
+    wall_g, _ = timed_loop(env_g, pool, gsteps, args.k, barrier, stream, torch, every=(ge, do_gather))
+    n_g = len(gathers) - n_before
+    red_p = r6dist.reduce_bench_times(wall_plain, first_us, device=dev)      # (the kernel_ms slot carries first_us)
+    red_g = r6dist.reduce_bench_times(wall_g, 0.0, device=dev)
+    wp, wg = red_p["wall_max"], red_g["wall_max"]
+    return {"gather_every": ge, "steps": gsteps, "gathers": n_g, "wall_s": wg, "unit": "env-steps/s",
+            "us_per_step_tracked_env": wp / gsteps * 1e6, "us_per_step_with_gathers": wg / gsteps * 1e6,
+            "us_per_gather": (wg - wp) / max(n_g, 1) * 1e6, "first_gather_us": red_p["kernel_ms_max"],
+            "warm": "one untimed pass with 2 gathers before both timed loops; same env, same steps",
+            "episodes_seen": float(sum(float(t[:, 0].sum()) for t in gathers[n_before:]))}
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.k > 1 and args.steps % args.k:
@@ -343,8 +472,16 @@ def main(argv=None):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: do not depend on the hostname resolving
         try:
             host_group = dist.new_group(backend="gloo")
-        except Exception as e:                                     # the same on every rank of the node: RCCL barriers then
-            print(f"[bench] gloo group unavailable ({e}); barriers through RCCL", file=sys.stderr)
+        except Exception as e:
+            print(f"[bench] rank {rank}: gloo group unavailable ({e})", file=sys.stderr)
+            host_group = None
+        # one decision for the whole job: a rank that waits on the gloo barrier while another one waits on an RCCL barrier
+        # hangs inside the timed region.  The ranks exchange an ok flag through the process group's key-value store (TCP, not
+        # a collective of either backend) and take gloo only if every rank has it.
+        if not r6dist.all_ranks_agree(host_group is not None, "bench_gloo_ok"):
+            if rank == 0:
+                print("[bench] no gloo group on some rank: barriers through RCCL on every rank", file=sys.stderr)
+            host_group = None
             rccl_live[0] = True
 
     def barrier():
@@ -368,31 +505,28 @@ def main(argv=None):
         red = r6dist.reduce_bench_times(wall, kernel_ms, device=dev)
         wall, kernel_ms = red["wall_max"], red["kernel_ms_max"]
         # the one collective of the design (episode summaries) inside a second, short timed loop:
-        # BASELINE configs[4]'s per-rollout exchange
-        gsteps = max(args.gather_every, min(args.steps, 10 * args.gather_every) // args.gather_every * args.gather_every)
-        gathers = []     # per-rank tables stay on the device: the all-gather is stream-ordered, the loop never drains the GPU
-        # its own env, with the episode accounting the summaries come from (ep_step / ep_return rows, +16 B per env-step and
-        # the statistics: ~45 us per step against the headline's ~38): the headline loop above stays the raw step at every N,
-        # so that the driver's scaling ratios compare like with like
+        # BASELINE configs[4]'s per-rollout exchange.  Its own env, with the episode accounting the summaries come from
+        # (ep_step / ep_return rows, +16 B per env-step and the statistics): the headline loop above stays the raw step at
+        # every N, so that the driver's scaling ratios compare like with like
         env_g = env if wrapped else BatchedRocket6DOF(
             n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=rank * n, auto_reset=True,
             record_flags=False, record_terms=False, track_episodes=True, seed=42)
         if env_g is not env:
             env_g.reset()
-            for j in range(min(args.burnin, 400)):
-                env_g.step_async(pool[j % args.pool]) if args.k <= 1 else None
-            if args.k > 1:
-                env_g.step_k(pool[0], last_only=True)
+            if args.k <= 1:
+                for j in range(args.burnin):
+                    env_g.step_async(pool[j % args.pool])
+            else:
+                for j in range(max(1, args.burnin // args.k)):
+                    env_g.step_k(pool[j % args.pool], last_only=True)
                 env_g._bench_out = env_g.step_k(pool[0])
-        wall_g, _ = timed_loop(env_g, pool, gsteps, args.k, barrier, stream, torch,
-                               every=(args.gather_every, lambda: gathers.append(r6dist.gather_episode_stats_device(env_g.episode_stats_tensor()))))
-        redg = r6dist.reduce_bench_times(wall_g, 0.0, device=dev)
+        gather = rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev)
+        gather["value"] = n * world * gather["steps"] / gather.pop("wall_s")
         extras["rccl"] = {"backend": backend, "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
                           "kernel_us_min": red["kernel_ms_min"] * 1e3, "kernel_us_max": red["kernel_ms_max"] * 1e3,
                           "wall_s_min": red["wall_min"], "wall_s_max": red["wall_max"],
-                          "with_rollout_gather": {"gather_every": args.gather_every, "steps": gsteps, "gathers": len(gathers),
-                                                  "value": n * world * gsteps / redg["wall_max"], "unit": "env-steps/s",
-                                                  "episodes_seen": float(sum(float(t[:, 0].sum()) for t in gathers))}}
+                          "verified_with_more_than_one_rank": dist.get_world_size() > 1,
+                          "with_rollout_gather": gather}
 
     if rank == 0:
         dt = args.dt or cfg["timestep"]

@@ -284,8 +284,8 @@ int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std
  * value head (R6PolicyNet.shared = 1, hidden (128, 64)), and SB3's default, two separate tanh MLPs obs -> 64 -> 64
  * (shared = 0, hidden (64, 64); BASELINE configs[4] "SB3 PPO MLP(64,64)").
  *   obs (rows, obs_dim), action (rows, 3), old_logp / adv / ret [rows]: the rollout buffer; `index` [n] (int64, or NULL for
- *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  Row numbers must be below 2^31 (they are kept as
- *   32-bit values one tile ahead of their use).  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
+ *   rows 0..n-1) picks the minibatch, so no gathered copies are needed.  n_rows = rows of the rollout tensors: with an index it
+ *   must be below 2^31 (row numbers are kept as 32-bit values one tile ahead of their use; R6_E_BADARG otherwise).  adv_norm = [mean, 1/(std + 1e-8)] or NULL.
  *   grad: WRITTEN (not accumulated), torch.nn.Linear layouts like the weights.  stats [16]: [0..7] written: pg_loss, v_loss,
  *   entropy, clip_frac, approx_kl, n; [8..15] += the same six (running sums over launches: the caller zeroes them when a new sum
  *   starts and reads means once per update).  scratch: r6_ppo_scratch_floats() floats of device memory owned by the caller. */
@@ -307,9 +307,9 @@ int r6_minibatch_adv_norm(const float *adv, const int64_t *index, int64_t n, int
                           void *stream);
 size_t r6_ppo_scratch_floats(void);
 int r6_ppo_minibatch_grad(const R6PolicyNet *net, const float *obs, const float *action, const float *old_logp,
-                          const float *adv, const float *ret, const int64_t *index, int64_t n, const float *adv_norm,
-                          float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad *grad, float *stats,
-                          float *scratch, size_t scratch_floats, void *stream);
+                          const float *adv, const float *ret, const int64_t *index, int64_t n, int64_t n_rows,
+                          const float *adv_norm, float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad *grad,
+                          float *stats, float *scratch, size_t scratch_floats, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(params, max_grad_norm) + torch.optim.Adam.step() (SB3 1.6's optimiser step, with its
  * eps 1e-5) for a policy whose parameters / gradients / Adam moments are FLAT device arrays of n floats, in one launch.

@@ -59,7 +59,7 @@ def load(path: str | None = None):
     lib.r6_ppo_loss_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp, vp]
     lib.r6_policy_grad_size.restype = C.c_size_t
     lib.r6_ppo_scratch_floats.restype = C.c_size_t
-    lib.r6_ppo_minibatch_grad.argtypes = [C.POINTER(R6PolicyNet), vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32,
+    lib.r6_ppo_minibatch_grad.argtypes = [C.POINTER(R6PolicyNet), vp, vp, vp, vp, vp, vp, i64, i64, vp, f32, f32, f32,
                                           C.POINTER(R6PolicyGrad), vp, vp, C.c_size_t, vp]
     lib.r6_ppo_minibatch_grad.restype = C.c_int
     lib.r6_minibatch_adv_norm.argtypes = [vp, vp, i64, i64, vp, vp, vp]

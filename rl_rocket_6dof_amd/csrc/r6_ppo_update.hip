@@ -1052,15 +1052,21 @@ extern "C" size_t r6_ppo_scratch_floats(void) { return (size_t)256 * r6u::kParti
 extern "C" size_t r6_policy_grad_size(void) { return sizeof(R6PolicyGrad); }
 
 extern "C" int r6_ppo_minibatch_grad(const R6PolicyNet* net, const float* obs, const float* action, const float* old_logp,
-                                     const float* adv, const float* ret, const int64_t* index, int64_t n, const float* adv_norm,
-                                     float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad* grad, float* stats,
-                                     float* scratch, size_t scratch_floats, void* stream) {
+                                     const float* adv, const float* ret, const int64_t* index, int64_t n, int64_t n_rows,
+                                     const float* adv_norm, float clip_range, float vf_coef, float ent_coef, const R6PolicyGrad* grad,
+                                     float* stats, float* scratch, size_t scratch_floats, void* stream) {
     if (!net || !obs || !action || !old_logp || !adv || !ret || !grad || !stats || !scratch) {
         r6_internal_set_error("r6_ppo_minibatch_grad: all pointers except index and adv_norm are required");
         return R6_E_BADARG;
     }
     if (n <= 0 || n >= ((int64_t)1 << 31)) {
         r6_internal_set_error("r6_ppo_minibatch_grad: need 0 < n < 2^31");
+        return R6_E_BADARG;
+    }
+    // the kernel keeps the gathered row numbers as 32-bit values (one tile ahead of their use): a rollout buffer with 2^31 rows
+    // or more (e.g. 2^20 envs x 2048 steps) would silently gather the wrong rows
+    if (n_rows < n || (index && n_rows >= ((int64_t)1 << 31))) {
+        r6_internal_set_error("r6_ppo_minibatch_grad: need n <= n_rows, and n_rows < 2^31 when an index is given");
         return R6_E_BADARG;
     }
     const R6PolicyNet& p = *net;

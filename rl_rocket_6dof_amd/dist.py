@@ -53,6 +53,20 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def all_ranks_agree(ok: bool, key: str) -> bool:
+    """True iff EVERY rank passed ok=True.  Goes through the default process group's key-value store (the TCP rendezvous
+    store), not through a collective of any backend -- usable to decide which backend's collectives to use next.  Without a
+    process group: ``ok``."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
+    from torch.distributed import distributed_c10d as c10d
+
+    store = c10d._get_default_store()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    store.set(f"r6/{key}/{rank}", "1" if ok else "0")
+    return all(store.get(f"r6/{key}/{r}") == b"1" for r in range(world))     # get() blocks until the key exists
+
+
 def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str, float], torch.Tensor]:
     """All-gathers the per-rank episode summaries (``BatchedRocket6DOF.episode_stats()``).
     Returns (global totals, per-rank table [world, NUM_STATS])."""

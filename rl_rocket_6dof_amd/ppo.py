@@ -228,10 +228,14 @@ class FusedMinibatchGrad:
         for name, t in zip(self._net_names, self.params):
             setattr(net, name, t.data_ptr())
         n = int(index.numel()) if index is not None else int(obs.shape[0])
+        n_rows = int(obs.shape[0])
+        if index is not None and n_rows >= 1 << 31:
+            raise ValueError(f"rollout buffer of {n_rows} rows: the fused minibatch gradient gathers rows through 32-bit row numbers "
+                             "(< 2^31 rows); use a smaller n_steps x num_envs per rank")
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         with torch.cuda.device(self.device):
             rc = self.lib.r6_ppo_minibatch_grad(C.byref(net), ptr(obs), ptr(action), ptr(old_logp), ptr(adv), ptr(ret), ptr(index), n,
-                                                ptr(adv_norm), float(clip), float(vf_coef), float(ent_coef), C.byref(self._grad),
+                                                n_rows, ptr(adv_norm), float(clip), float(vf_coef), float(ent_coef), C.byref(self._grad),
                                                 ptr(self.stats), ptr(self.scratch), self.scratch.numel(),
                                                 C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         from . import _lib
@@ -439,9 +443,9 @@ class PPO:
                 self.buf_boot = torch.zeros((T, n), **f32) if self._time_limit else None
                 # env outputs land directly in the rollout buffer when its rows are 16-byte aligned (BatchedRocket6DOF.step_into)
                 self._direct = hasattr(env, "step_into") and (n * env.obs_dim) % 4 == 0 and not getattr(env, "numpy_io", False)
+                # device-resident part of the step counters (graph replays): attached to the env only while the rollout's
+                # launches are issued or recorded -- an eager env.step() between rollouts must not add a stale base
                 self._step_base = torch.zeros((), dtype=torch.int64, device=self.device)
-                if self._direct:
-                    env.set_step_base(self._step_base)
 
     def _all_reduce(self, t: torch.Tensor, op=None) -> torch.Tensor:
         """Sum (default) over ranks of a small host tensor: through the device for RCCL, on the host for gloo."""
@@ -467,6 +471,16 @@ class PPO:
         truncated row are skipped on the device); then V(last obs) and ``r6_gae``."""
         env, cfg, T = self.env, self.cfg, self.cfg.n_steps
         base = self._step_base
+        env.set_step_base(base)
+        try:
+            self._rollout_steps(env, T, base)
+        finally:
+            env.set_step_base(None)
+        bo = self._boot_out
+        self.fused(self._obs, deterministic=True, step_index=0, out=(bo[0], bo[1], self._last_val, bo[3]))
+        self._gae(self._last_val)
+
+    def _rollout_steps(self, env, T, base):
         self.buf_obs[0].copy_(self._obs)
         for t in range(T):
             self._rollout_step += 1
@@ -478,9 +492,6 @@ class PPO:
                 bo = self._boot_out
                 self.fused(env.final_obs, deterministic=True, step_index=0, out=(bo[0], bo[1], self.buf_boot[t], bo[3]),
                            row_flags=self.buf_flags[t], flag_mask=FLAG_TRUNCATED)
-        bo = self._boot_out
-        self.fused(self._obs, deterministic=True, step_index=0, out=(bo[0], bo[1], self._last_val, bo[3]))
-        self._gae(self._last_val)
 
     def _gae(self, last_values):
         """GAE(lambda) into ``self.adv`` / ``self.ret``: one launch of ``r6_gae`` on the GPU (time-limit bootstrap folded
@@ -513,16 +524,23 @@ class PPO:
             self._in_kernel_bootstrap = True
             if cfg.graph_rollout and self._rollouts >= 1:        # the first rollout runs eagerly (one-time set-up in the launch paths)
                 if self._rollout_graph is None:
-                    # recording runs the Python side once (the host step counters advance by T, nothing executes);
-                    # every replay then continues the RNG streams through the device-side base instead
+                    # recording runs the Python side once and executes nothing: the launches keep the step counters they
+                    # were recorded with (c0 + 1 .. c0 + T) for ever, and the host counters are put back afterwards
+                    self._graph_c0, self._graph_r0 = env._step_count, self._rollout_step
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._rollout_launches()
-                        self._step_base.add_(T)
                     self._rollout_graph = g
-                    self._step_base.zero_()
+                    env._step_count, self._rollout_step = self._graph_c0, self._graph_r0
+                # every replay continues the RNG streams through the device-side base, set from the HOST counter: eager
+                # env.step / step_k / evaluation calls between rollouts advance that counter too, so no (env, step) key of the
+                # reset stream is ever drawn twice, and the host counters (LazyInfos' staleness check reads them) stay true
+                self._step_base.fill_(env._step_count - self._graph_c0)
                 self._rollout_graph.replay()
+                env._step_count += T
+                self._rollout_step += T
             else:
+                self._step_base.zero_()
                 self._rollout_launches()
             self._rollouts += 1
             self.num_timesteps += cfg.n_steps * self.global_envs

@@ -76,6 +76,53 @@ def pure_rel_err(a, b, scale, floor=0.05):
     return float((np.abs(a - b)[m] / np.abs(b[m])).max()) if m.any() else 0.0
 
 
+def reward_rel_err(rew, rew_ref, terms_ref, floor=0.05, scale=1.0):
+    """The literal 1e-5-relative bound for the total reward, read the way a SUM has to be read: the reward is the sum of seven
+    terms of mixed sign (eta = +0.1 per step against a tracking term of about -0.1; goal / final-velocity terms of +10 and more
+    against the attitude penalty of -10), so |reward| can be orders of magnitude below its summands and |error| / |reward| then
+    measures the cancellation, not the computation.  Each row is judged against max(|reward|, largest |term| of the row); rows
+    whose reference is tiny even on that measure (below floor * scale) are left to the scaled bound.  Returns the worst ratio."""
+    rew = np.asarray(rew, dtype=np.float64)
+    rew_ref = np.asarray(rew_ref, dtype=np.float64)
+    mag = np.maximum(np.abs(rew_ref), np.abs(np.asarray(terms_ref, dtype=np.float64)).max(axis=1))
+    m = mag >= floor * scale
+    return float((np.abs(rew - rew_ref)[m] / mag[m]).max()) if m.any() else 0.0
+
+
+def ks_two_sample(a, b):
+    """Two-sample Kolmogorov-Smirnov distance sup |F_a - F_b| and its critical value at alpha = 0.001
+    (1.95 * sqrt((n + m) / (n m)))."""
+    a, b = np.sort(np.asarray(a, np.float64)), np.sort(np.asarray(b, np.float64))
+    allv = np.concatenate([a, b])
+    d = np.abs(np.searchsorted(a, allv, side="right") / len(a) - np.searchsorted(b, allv, side="right") / len(b)).max()
+    return float(d), 1.95 * np.sqrt((len(a) + len(b)) / (len(a) * len(b)))
+
+
+def check_reset_sample_against_reference_draws(states, what):
+    """`states` (n, 14): initial conditions from the build's reset.  Compared, as a sample, with golden G12 -- 50 000 initial
+    conditions drawn by the REFERENCE's own Rocket6DOF.reset() (rocket_env.py:180-199): per component two-sample KS at
+    alpha = 0.001, means within 5 standard errors, constant components identical, quaternion unit, and the correlation
+    structure the quaternion normalisation creates."""
+    G = load_golden("g12_reset_draws.npz")
+    ref = G["state"].astype(np.float64)
+    st = np.asarray(states, np.float64)
+    worst = 0.0
+    for j in range(14):
+        if ref[:, j].std() == 0.0:
+            assert np.all(st[:, j] == ref[0, j]), f"{what}: component {j} is constant in the reference's draws"
+            continue
+        d, crit = ks_two_sample(st[:, j], ref[:, j])
+        worst = max(worst, d / crit)
+        assert d < crit, f"{what}: component {j}: KS distance {d:.4f} >= {crit:.4f}"
+        se = np.sqrt(ref[:, j].var() / len(ref) + st[:, j].var() / len(st))
+        assert abs(st[:, j].mean() - ref[:, j].mean()) < 5 * se, f"{what}: component {j} mean"
+        assert abs(st[:, j].std() / ref[:, j].std() - 1) < 0.03, f"{what}: component {j} spread"
+    assert np.abs(np.linalg.norm(st[:, 6:10], axis=1) - 1).max() < 1e-6
+    ca, cb = np.corrcoef(st[:, 6:10].T), np.corrcoef(ref[:, 6:10].T)
+    assert np.abs(ca - cb).max() < 0.03, f"{what}: quaternion correlation structure"
+    return worst
+
+
 def _log_key(what):
     import re
 

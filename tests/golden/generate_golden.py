@@ -33,6 +33,10 @@ What each file pins (reference file:line):
                    ICRange, every reward coefficient changed incl. a non-zero w_r_f, tighter trajectory / landing limits, a
                    different landing radius and velocity): pins the host-side digestion of env_config (rocket_env.py:22-178)
                    and the parameters' way through the kernel beyond the one shipped configuration   (--only g11)
+  g12_reset_draws   50 000 initial conditions drawn by the reference's own Rocket6DOF.reset() (rocket_env.py:180-199: init_space.sample(),
+                   quaternion normalised, new Simulator6DOF) after seed(2022): the simulator state of each fresh episode, float32 --
+                   a SAMPLE of the reset distribution (gym's RNG stream itself is not reproducible without gym 0.21: Box.sample
+                   here is the loader's gym-0.21 restatement, np_random.uniform(low, high))   (--only g12)
   g9_shipped_policy_in_reference   the policy trained on the HIP env (examples/policies/) flown in the REFERENCE
                    env: 16 episodes, terminal states, landing flags   (--only g9)
 """
@@ -424,7 +428,24 @@ def gen_g11():
     np.savez_compressed(os.path.join(HERE, "g11_other_configs.npz"), meta=_meta(), **out)
 
 
+def gen_g12(n=50000):
+    Sim, Env, cfg = load_reference()
+    env = Env(**cfg)
+    env.seed(2022)
+    out = np.zeros((n, 14), np.float32)
+    obs = np.zeros((n, 14), np.float32)
+    for i in range(n):
+        obs[i] = env.reset()                                   # rocket_env.py:180-199
+        out[i] = np.asarray(env.SIM.state, np.float64)          # the fresh simulator's state
+    np.savez_compressed(os.path.join(HERE, "g12_reset_draws.npz"), state=out, obs_first=obs[:256], config=np.array(json.dumps(cfg)),
+                        meta=_meta({"seed": 2022, "n": n}))
+    print("G12", out.shape, "mean", out.mean(0).round(3), "min", out.min(0).round(3), "max", out.max(0).round(3))
+
+
 def main():
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g12":
+        gen_g12()
+        return
     if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "g11":
         gen_g11()
         return

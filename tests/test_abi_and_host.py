@@ -93,9 +93,13 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     net, grad = R6PolicyNet(), R6PolicyGrad()
     net.obs_dim, net.hidden1, net.hidden2, net.shared = 13, 256, 64, 1                    # unsupported topology
     fake = C.c_void_p(64)
-    assert lib.r6_ppo_minibatch_grad(C.byref(net), fake, fake, fake, fake, fake, None, 32, None, 0.2, 0.5, 0.0, C.byref(grad), fake, fake,
+    assert lib.r6_ppo_minibatch_grad(C.byref(net), fake, fake, fake, fake, fake, None, 32, 32, None, 0.2, 0.5, 0.0, C.byref(grad), fake, fake,
                                      1 << 20, None) == -10001
     assert b"supported nets" in lib.r6_last_error()
+    # a rollout buffer of 2^31 rows or more cannot be indexed (32-bit row numbers in the kernel): rejected, not mis-gathered
+    assert lib.r6_ppo_minibatch_grad(C.byref(net), fake, fake, fake, fake, fake, fake, 32, 1 << 31, None, 0.2, 0.5, 0.0, C.byref(grad), fake,
+                                     fake, 1 << 20, None) == -10001
+    assert b"n_rows" in lib.r6_last_error()
     assert lib.r6_policy_act(C.byref(net), None, 32, None, None, None, None, 0, 1, None, 0, 0, None, 0, None) == -10001
 
 

@@ -32,6 +32,10 @@ def test_line_contract_single_gpu():
     assert abs(r["achieved"] - 189 * n / 37.5e-6 / 1e9) < 1e-6 * r["achieved"] and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert r["traffic_source"].startswith("profiles/") and abs(r["kernel_us"] - 37.5) < 1e-9
     assert "model" not in line["config"] and "workload" in line["config"]
+    # record hygiene (round 3): the library's build stamp and this file's digest, each named for what it is
+    assert "commit" not in line["config"] and "lib_commit" in line["config"]
+    import hashlib
+    assert line["config"]["bench_py_sha16"] == hashlib.sha256(open(os.path.join(ROOT, "bench.py"), "rb").read()).hexdigest()[:16]
 
 
 def test_bytes_per_env_step_formula():
@@ -64,6 +68,9 @@ def _worker(rank, world, port, q):
     # what main() does after its timed loops, with the GPU part replaced by fixed per-rank numbers
     wall, kernel_ms = (0.080, 0.0380) if rank == 0 else (0.084, 0.0402)
     red = r6dist.reduce_bench_times(wall, kernel_ms)
+    # the gloo-or-RCCL decision of bench.py is a GROUP decision: one rank without a gloo group switches every rank
+    assert r6dist.all_ranks_agree(True, "t1") is True
+    assert r6dist.all_ranks_agree(rank != 1, "t2") is False
     tot, _ = r6dist.gather_episode_stats({k: float(rank + 1) for k in r6dist.STAT_NAMES})
     args = b.parse_args(["--gpus", "2", "--steps", "2000", "--warmup", "100"])
     extras = {"rccl": {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
@@ -107,3 +114,54 @@ def test_valu_object_from_the_committed_profile():
     assert bench.valu_from_profile("raw", "euler", 1 << 20, 1, 0.0375) is None
     assert bench.valu_from_profile("raw", "rk4", 1 << 16, 1, 0.0375) is None
     assert bench.valu_from_profile("raw", "rk4", 1 << 20, 16, 0.0375) is None
+
+
+def test_rollout_gather_loop_is_warmed_and_itemised(monkeypatch):
+    """bench.py's N > 1 second loop (BASELINE configs[4]'s per-rollout all-gather): the first gather is timed alone, one
+    untimed pass with two gathers warms the path, then the same steps run without and with gathers on the same env and the
+    record carries the difference per gather.  GPU-free: the timed loop and the env are stand-ins."""
+    import types
+
+    import torch
+
+    calls = []
+
+    class FakeEnv:
+        def episode_stats_tensor(self):
+            return torch.arange(8, dtype=torch.float64)
+
+    def fake_timed_loop(env, pool, steps, k, barrier, stream, torch_mod, every=None):
+        n_cb = 0
+        if every is not None:
+            for j in range(steps):
+                if (j + 1) % every[0] == 0:
+                    every[1]()
+                    n_cb += 1
+        calls.append((steps, n_cb))
+        return steps * 45e-6 + n_cb * 30e-6, 0.045
+
+    monkeypatch.setattr(bench, "timed_loop", fake_timed_loop)
+    from rl_rocket_6dof_amd import dist as r6dist
+
+    args = bench.parse_args(["--gpus", "2", "--steps", "2000"])
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(synchronize=lambda dev=None: None))
+    g = bench.rollout_gather_loop(FakeEnv(), [None, None], args, lambda: None, None, fake_torch, r6dist, None)
+    assert calls == [(64, 2), (320, 0), (320, 10)]                     # warm pass with 2 gathers, then plain, then with gathers
+    for key in ("gather_every", "steps", "gathers", "wall_s", "us_per_step_tracked_env", "us_per_step_with_gathers", "us_per_gather",
+                "first_gather_us", "warm", "episodes_seen"):
+        assert key in g, key
+    assert g["gathers"] == 10 and g["steps"] == 320
+    assert g["us_per_gather"] == pytest.approx(30.0, rel=1e-6) and g["us_per_step_tracked_env"] == pytest.approx(45.0, rel=1e-6)
+    assert g["first_gather_us"] >= 0.0
+
+
+def test_all_ranks_agree_without_a_process_group():
+    from rl_rocket_6dof_amd import dist as r6dist
+
+    assert r6dist.all_ranks_agree(True, "k") is True and r6dist.all_ranks_agree(False, "k") is False
+
+
+def test_cpu_baseline_all_cores_reports_cores_and_model():
+    r = bench.cpu_baseline_all_cores(1.0, max_procs=2)
+    assert "error" not in r, r
+    assert r["cores"] == min(2, bench.usable_cores()) and r["value"] > 0 and r["cpu_model"] and "independent processes" in r["sample"]

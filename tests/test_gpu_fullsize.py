@@ -273,6 +273,31 @@ def test_fuzz_wide_state_ranges_vs_c_oracle(torch_cuda, cfg, integ, shaping):
 
 
 
+def test_reset_against_the_references_own_draws():
+    """a23, Rocket6DOF.reset (rocket_env.py:180-199, init_space :78-81): 2^20 HIP resets, as a sample, beside golden G12 -- 50 000
+    initial conditions drawn by the reference's own reset() in the golden generator (two-sample KS per component, means, spreads,
+    constant components, quaternion rule)."""
+    from conftest import check_reset_sample_against_reference_draws
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+
+    env = BatchedRocket6DOF(1 << 20, default_env_config(), seed=321)
+    env.reset()
+    w = check_reset_sample_against_reference_draws(env.get_state().cpu().numpy(), "HIP reset")
+    print(f"[G12] HIP reset vs the reference's draws: worst KS distance / critical value {w:.2f}")
+    # in-kernel auto-reset draws (another counter range of the same stream): the states of envs that have just been re-sampled
+    env2 = BatchedRocket6DOF(1 << 18, default_env_config(), seed=5, max_episode_steps=1)     # every env ends after its first step
+    env2.reset()
+    env2.step(torch_zero_actions(env2))
+    w2 = check_reset_sample_against_reference_draws(env2.get_state().cpu().numpy(), "HIP in-kernel reset")
+    print(f"[G12] HIP in-kernel reset vs the reference's draws: {w2:.2f}")
+
+
+def torch_zero_actions(env):
+    import torch
+
+    return torch.zeros((env.num_envs, 3), device=env.device)
+
+
 def test_reset_distribution_matches_the_reference_rule():
     """Rocket6DOF.reset (rocket_env.py:180-199, init_space :78-81): every component ~ U(IC - ICRange/2, IC + ICRange/2)
     independently, quaternion normalised afterwards.  gym's RNG stream cannot be reproduced (reset

@@ -5,7 +5,7 @@ import json
 import numpy as np
 import pytest
 
-from conftest import assert_close_scaled, load_golden
+from conftest import assert_close_scaled, load_golden, pure_rel_err, reward_rel_err
 from oracle import oracle_c as oc
 from oracle import oracle_np as onp
 
@@ -47,6 +47,10 @@ def test_env_step_vs_reference(cfg, P, fixture):
     assert_close_scaled(obs, G["obs"], 1.0, 2e-6, "C obs vs reference")
     assert_close_scaled(env.terms, G["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference")
     assert_close_scaled(rew, G["reward"], 1e-1, 2e-5, "C reward vs reference")
+    # the literal 1e-5: per term, and for the total against the largest of its own summands (a cancelled sum -- golden G4 row
+    # 1179: +10.013 final_velocity against -10 attitude_constraint, reward -0.218 -- shows 1.3e-5 on |reward| alone)
+    assert pure_rel_err(env.terms, G["terms"], TERM_SCALE) < 1e-5
+    assert reward_rel_err(rew, G["reward"], G["terms"]) < 1e-5
 
 
 def test_g5_reward(cfg, P, g5):
@@ -85,6 +89,18 @@ def test_reset_stream_bit_exact_with_numpy_oracle(cfg, P):
         plain = [0, 1, 2, 3, 4, 5, 10, 11, 12, 13]
         np.testing.assert_array_equal(env.state[i, plain].astype(np.float32), want[plain])
         np.testing.assert_allclose(env.state[i, 6:10], want[6:10], atol=1.2e-7)
+
+
+def test_reset_stream_against_the_references_own_draws(cfg):
+    """Rocket6DOF.reset (rocket_env.py:180-199): the build's counter-based reset stream, as a sample, beside golden G12 -- 50 000
+    initial conditions drawn by the reference's own reset()."""
+    from conftest import check_reset_sample_against_reference_draws
+
+    n = 1 << 17
+    env = oc.BatchOracle(n, cfg, seed=7)
+    env.reset(step_index=(1 << 60) + 1)
+    w = check_reset_sample_against_reference_draws(env.state.astype(np.float32), "C oracle reset stream")
+    print(f"[G12] worst KS distance / critical value: {w:.2f}")
 
 
 def test_auto_reset_and_counters(cfg):
@@ -180,3 +196,5 @@ def test_g11_other_configs_vs_reference(tag):
     assert_close_scaled(obs, g["obs"], 1.0, 2e-6, "C obs vs reference (G11)")
     assert_close_scaled(env.terms, g["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference (G11)")
     assert_close_scaled(rew, g["reward"], 1e-1, 2e-5, "C reward vs reference (G11)")
+    assert pure_rel_err(env.terms, g["terms"], TERM_SCALE) < 1e-5
+    assert reward_rel_err(rew, g["reward"], g["terms"]) < 1e-5
