@@ -89,6 +89,20 @@ def reward_rel_err(rew, rew_ref, terms_ref, floor=0.05, scale=1.0):
     return float((np.abs(rew - rew_ref)[m] / mag[m]).max()) if m.any() else 0.0
 
 
+def term_rel_err(terms, terms_ref, coeff, term_scale, floor=0.05):
+    """The literal 1e-5-relative bound per reward TERM.  Terms 0-4 (tracking, thrust penalty, eta, attitude, goal): pure relative
+    error where the reference is not tiny against its natural scale.  Terms 5 and 6 are themselves differences,
+    w_r_f * (max_r_f - |r|) and w_v_f * (max_v_f - |v|) (rocket_env.py:400-401): next to the rim (|r| = 59.5 m of max_r_f = 60 m in
+    golden G11) the term is a cancelled difference of operands of size w * max, and it is judged against that size."""
+    t = np.asarray(terms, dtype=np.float64)[:, :7]
+    r = np.asarray(terms_ref, dtype=np.float64)[:, :7]
+    worst = pure_rel_err(t[:, :5], r[:, :5], np.asarray(term_scale, np.float64)[:5], floor)
+    for j, full in ((5, abs(coeff["w_r_f"] * coeff["max_r_f"])), (6, abs(coeff["w_v_f"] * coeff["max_v_f"]))):
+        if full > 0:
+            worst = max(worst, float((np.abs(t[:, j] - r[:, j]) / np.maximum(np.abs(r[:, j]), full)).max()))
+    return worst
+
+
 def ks_two_sample(a, b):
     """Two-sample Kolmogorov-Smirnov distance sup |F_a - F_b| and its critical value at alpha = 0.001
     (1.95 * sqrt((n + m) / (n m)))."""

@@ -12,7 +12,7 @@ import json
 import numpy as np
 import pytest
 
-from conftest import PARITY_LOG, assert_close_scaled, load_golden, pure_rel_err, reward_rel_err
+from conftest import PARITY_LOG, assert_close_scaled, load_golden, pure_rel_err, reward_rel_err, term_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -79,7 +79,7 @@ def _check_against_golden(env, obs, rew, done, G, P, what, tol=TOL_EVENTS):
     # within 1e-5 pure relative of the reference's, and so is the total against the largest of its own summands -- where
     # |reward| / |reward_ref| - 1 alone exceeds 1e-5 (golden G4 row 1179: 1.3e-5 even for the float64 oracle) the row is a
     # cancelled sum (final_velocity +10.013 against attitude_constraint -10 ...: reward -0.218) whose terms agree to 3e-7
-    pr_terms = pure_rel_err(terms, G["terms"][:, :7], TERM_SCALE)
+    pr_terms = term_rel_err(terms, G["terms"], env.reward_coefficients, TERM_SCALE)
     pr_rew = reward_rel_err(rew, G["reward"], G["terms"][:, :7])
     rec = PARITY_LOG.setdefault(f"{what}: reward, pure relative vs max(|reward|, largest |term|)", {"scaled": 0.0, "pure_rel": 0.0, "rtol": RTOL, "n": 0})
     rec["pure_rel"], rec["scaled"], rec["n"] = max(rec["pure_rel"], pr_rew), max(rec["scaled"], pr_rew), rec["n"] + len(rew)

@@ -5,7 +5,7 @@ import json
 import numpy as np
 import pytest
 
-from conftest import assert_close_scaled, load_golden, pure_rel_err, reward_rel_err
+from conftest import assert_close_scaled, load_golden, reward_rel_err, term_rel_err
 from oracle import oracle_c as oc
 from oracle import oracle_np as onp
 
@@ -49,7 +49,7 @@ def test_env_step_vs_reference(cfg, P, fixture):
     assert_close_scaled(rew, G["reward"], 1e-1, 2e-5, "C reward vs reference")
     # the literal 1e-5: per term, and for the total against the largest of its own summands (a cancelled sum -- golden G4 row
     # 1179: +10.013 final_velocity against -10 attitude_constraint, reward -0.218 -- shows 1.3e-5 on |reward| alone)
-    assert pure_rel_err(env.terms, G["terms"], TERM_SCALE) < 1e-5
+    assert term_rel_err(env.terms, G["terms"], cfg["reward_coeff"], TERM_SCALE) < 1e-5
     assert reward_rel_err(rew, G["reward"], G["terms"]) < 1e-5
 
 
@@ -196,5 +196,5 @@ def test_g11_other_configs_vs_reference(tag):
     assert_close_scaled(obs, g["obs"], 1.0, 2e-6, "C obs vs reference (G11)")
     assert_close_scaled(env.terms, g["terms"], TERM_SCALE, 2e-5, "C reward terms vs reference (G11)")
     assert_close_scaled(rew, g["reward"], 1e-1, 2e-5, "C reward vs reference (G11)")
-    assert pure_rel_err(env.terms, g["terms"], TERM_SCALE) < 1e-5
+    assert term_rel_err(env.terms, g["terms"], vcfg["reward_coeff"], TERM_SCALE) < 1e-5
     assert reward_rel_err(rew, g["reward"], g["terms"]) < 1e-5
