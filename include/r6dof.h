@@ -9,6 +9,7 @@
  *     my_environment/utils/simulator.py:69-104    Simulator6DOF.step     -> r6_sim_step
  *     my_environment/utils/simulator.py:106-143   Simulator6DOF.RHS      -> r6_rhs
  *     main_6DOF.py:107-139 / montecarlo_script.py  SB3 policy.forward / predict (the caller of step) -> r6_policy_act
+ *     main_6DOF.py:136-139  SB3 collect_rollouts: forward -> clip -> env.step, per timestep   -> r6_rollout (K steps, one launch)
  * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
  *
  * Conventions
@@ -253,6 +254,36 @@ size_t r6_policy_net_size(void); /* sizeof(R6PolicyNet) */
 int r6_policy_act(const R6PolicyNet *net, const float *obs, int64_t n, float *action, float *raw_action,
                   float *value, float *logp, uint64_t seed, uint64_t step_index, const uint64_t *step_base,
                   uint64_t env_offset, int deterministic, const uint8_t *row_flags, int flag_mask, void *stream);
+
+/* ---- K closed-loop rollout steps in one launch ------------------------------------------------------------------------
+ * The per-timestep loop of SB3's `OnPolicyAlgorithm.collect_rollouts` behind main_6DOF.py:136-139 -- policy.forward(obs), clip to
+ * the Box, env.step(action), and V(terminal_observation) for the envs a TimeLimit truncated -- K times, with the state of an env in
+ * registers throughout: the observation never leaves the CU between the env step and the forward that consumes it.
+ * Results are bit for bit those of the launch sequence  r6_policy_act(step j) -> r6_step(step j) [-> masked r6_policy_act]  for
+ * j = 0..k-1 with the same seeds and step counters.  All arrays are contiguous with a leading K dimension.
+ * R6Buffers supplies state / epconst / ep_step / ep_return / stats / step_base (in/out as in r6_step) and, optionally, final_obs /
+ * fin_return / fin_length (rows of finished envs, overwritten step after step as K r6_step calls would) and obs (the observation
+ * after the LAST step, = obs_seq row k); its action / reward / done / flags members are not used.
+ * Supported: R6PolicyNet hidden (64,64) | (128,64), obs_dim 13 | 14 equal to R6Params.obs_dim; euler / rk4 with n_substeps 1. */
+typedef struct R6Rollout {
+    int32_t k;              /* env steps in this launch, 1..65536 */
+    int32_t deterministic;  /* 0: sampled actions (training rollouts); 1: the mean action (evaluation, montecarlo_script.py) */
+    float *obs_seq;         /* (k+1, n, obs_dim) or NULL: row j+1 <- the observation after step j.  Row 0 is the caller's (the
+                               observation the first action is computed from: the kernel derives it from `state`, never reads it) */
+    float *raw_action;      /* (k, n, 3) or NULL: unclipped samples (what SB3's rollout buffer stores) */
+    float *value;           /* (k, n) or NULL */
+    float *logp;            /* (k, n) or NULL */
+    float *reward;          /* (k, n) */
+    uint8_t *done;          /* (k, n): exactly 0 or 1 */
+    uint8_t *flags;         /* (k, n) or NULL: R6_FLAG_* bits */
+    float *boot_value;      /* (k, n) or NULL: V(terminal observation) of the envs truncated in step j; other entries untouched */
+} R6Rollout;
+size_t r6_rollout_size(void);   /* sizeof(R6Rollout) */
+/* env_seed / env_step_index (+ *R6Buffers.step_base): the reset stream, as r6_step's seed / step_index of the first step;
+ * policy_seed / policy_step_index (+ *policy_step_base): the action-noise stream, as r6_policy_act's of the first step. */
+int r6_rollout(const R6Params *params, const R6Buffers *buf, const R6PolicyNet *net, const R6Rollout *rollout, uint64_t env_seed,
+               uint64_t env_step_index, uint64_t policy_seed, uint64_t policy_step_index, const uint64_t *policy_step_base,
+               uint64_t env_offset, void *stream);
 
 /* SB3 `RolloutBuffer.compute_returns_and_advantage` (GAE(lambda); stable_baselines3/common/buffers.py, called from
  * OnPolicyAlgorithm.collect_rollouts behind main_6DOF.py:136-139) for T steps of n envs in one launch, one lane per env:

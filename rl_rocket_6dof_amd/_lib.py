@@ -7,7 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .params import R6Buffers, R6Params, R6PolicyGrad, R6PolicyNet, R6StepK
+from .params import R6Buffers, R6Params, R6PolicyGrad, R6PolicyNet, R6Rollout, R6StepK
 
 ABI_VERSION = 6
 _LIBS = {}
@@ -15,7 +15,7 @@ _LIBS = {}
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad",
            "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad", "r6_minibatch_adv_norm", "r6_adam_clip_step",
-           "r6_gae", "r6_permutation", "r6_tune")
+           "r6_gae", "r6_permutation", "r6_tune", "r6_rollout", "r6_rollout_size")
 
 
 class R6Error(RuntimeError):
@@ -72,6 +72,12 @@ def load(path: str | None = None):
     lib.r6_permutation.restype = C.c_int
     lib.r6_tune.argtypes = [C.c_char_p, C.c_double]
     lib.r6_tune.restype = C.c_int
+    lib.r6_rollout_size.restype = C.c_size_t
+    lib.r6_rollout.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), C.POINTER(R6PolicyNet), C.POINTER(R6Rollout), u64, u64, u64, u64,
+                               vp, u64, vp]
+    lib.r6_rollout.restype = C.c_int
+    if lib.r6_rollout_size() != C.sizeof(R6Rollout):
+        raise ImportError("R6Rollout layout mismatch between params.py and libr6dof.so: rebuild")
     if lib.r6_policy_grad_size() != C.sizeof(R6PolicyGrad):
         raise ImportError("R6PolicyGrad layout mismatch between params.py and libr6dof.so: rebuild")
     for name in ("r6_step", "r6_step_k", "r6_reset", "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_act", "r6_ppo_loss_grad"):

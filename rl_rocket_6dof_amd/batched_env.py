@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .compat import Box, VecEnv
 from .params import (ACTION_DIM, K_LAST_ONLY, MAX_BLOCKS, FLAG_BOUNDS, FLAG_GROUND, FLAG_TRUNCATED, NUM_STATS, NUM_TERMS,
-                     STATE_DIM, STAT_NAMES, R6Buffers, R6StepK, default_env_config, make_params)
+                     STATE_DIM, STAT_NAMES, R6Buffers, R6Rollout, R6StepK, default_env_config, make_params)
 
 TERM_NAMES_ACC = ("atarg_tracking", "thrust_penalty", "eta", "attitude_constraint", "goal_conditions",
                   "final_position", "final_velocity",          # rocket_env.py:342-359
@@ -378,6 +378,45 @@ class BatchedRocket6DOF(VecEnv):
         self._step_count += K
         self._pending = a
         return res
+
+    def rollout(self, policy, k: int, *, reward: torch.Tensor, done: torch.Tensor, obs_seq: Optional[torch.Tensor] = None,
+                raw_action: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None, logp: Optional[torch.Tensor] = None,
+                flags: Optional[torch.Tensor] = None, boot_value: Optional[torch.Tensor] = None, deterministic: bool = False,
+                policy_step_index: int = 1, policy_step_base: Optional[torch.Tensor] = None) -> None:
+        """``k`` closed-loop rollout steps in ONE launch (``r6_rollout``): per step the policy forward of ``policy`` (a
+        ``policy.FusedActorCritic``), the clip to the action Box, this env's step, and V(terminal observation) for the envs a
+        time limit truncated -- SB3's ``collect_rollouts`` loop behind main_6DOF.py:136-139.  Bit for bit the sequence
+        ``policy.forward(obs, step_index=policy_step_index + j)`` -> ``step_into`` [-> masked forward] for j = 0..k-1.
+        All outputs are contiguous device tensors with a leading ``k`` dimension: ``reward`` (k, N) float32, ``done`` (k, N) uint8,
+        and optionally ``obs_seq`` (k + 1, N, obs_dim) (row j + 1 <- the observation after step j; row 0 is left alone),
+        ``raw_action`` (k, N, 3), ``value`` / ``logp`` (k, N), ``flags`` (k, N) uint8, ``boot_value`` (k, N) (written only where a
+        step truncated an env).  ``env.obs`` receives the observation after the last step."""
+        n, od, dev = self.num_envs, self.obs_dim, self.device
+        if policy.obs_dim != od or policy.device != dev:
+            raise ValueError("policy and env disagree on obs_dim / device")
+
+        def chk(t, name, shape, dtype):
+            if t is None:
+                return None
+            if t.device != dev or t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous():
+                raise ValueError(f"rollout: {name} must be a contiguous {dtype} {shape} tensor on {dev}")
+            return C.c_void_p(t.data_ptr())
+
+        ro = R6Rollout(k=int(k), deterministic=int(bool(deterministic)))
+        ro.reward, ro.done = chk(reward, "reward", (k, n), torch.float32), chk(done, "done", (k, n), torch.uint8)
+        ro.obs_seq = chk(obs_seq, "obs_seq", (k + 1, n, od), torch.float32)
+        ro.raw_action = chk(raw_action, "raw_action", (k, n, 3), torch.float32)
+        ro.value, ro.logp = chk(value, "value", (k, n), torch.float32), chk(logp, "logp", (k, n), torch.float32)
+        ro.flags, ro.boot_value = chk(flags, "flags", (k, n), torch.uint8), chk(boot_value, "boot_value", (k, n), torch.float32)
+        if policy_step_base is not None and (policy_step_base.dtype != torch.int64 or policy_step_base.device != dev or policy_step_base.numel() != 1):
+            raise ValueError("policy_step_base must be an int64 scalar tensor on the env's device")
+        net = policy._net()
+        with torch.cuda.device(dev):
+            rc = self.lib.r6_rollout(C.byref(self.params), C.byref(self._buf), C.byref(net), C.byref(ro), self._seed, self._step_count + 1,
+                                     policy.seed, int(policy_step_index), None if policy_step_base is None else C.c_void_p(policy_step_base.data_ptr()),
+                                     self.env_offset, self._stream())
+        _lib.check(rc, "r6_rollout", self.lib)
+        self._step_count += int(k)
 
     # ------------------------------------------------------------------------------------------
     def get_state(self) -> torch.Tensor:

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libr6dof.so")
-SOURCES = ["r6_kernels.hip", "r6_policy.hip", "r6_ppo_update.hip"]
+SOURCES = ["r6_kernels.hip", "r6_policy.hip", "r6_ppo_update.hip", "r6_rollout.hip"]
 
 
 def _headers():

@@ -80,6 +80,15 @@ class R6StepK(C.Structure):
     ]
 
 
+class R6Rollout(C.Structure):
+    """include/r6dof.h ``R6Rollout``: K closed-loop rollout steps per launch; contiguous (k, n, .) arrays."""
+    _fields_ = [
+        ("k", C.c_int32), ("deterministic", C.c_int32),
+        ("obs_seq", C.c_void_p), ("raw_action", C.c_void_p), ("value", C.c_void_p), ("logp", C.c_void_p),
+        ("reward", C.c_void_p), ("done", C.c_void_p), ("flags", C.c_void_p), ("boot_value", C.c_void_p),
+    ]
+
+
 class R6PolicyNet(C.Structure):
     """include/r6dof.h ``R6PolicyNet``: device pointers to fp32 weights in torch.nn.Linear layout."""
     _fields_ = [

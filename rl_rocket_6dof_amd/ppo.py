@@ -65,6 +65,8 @@ class PPOConfig:
                                      # net shape is supported and the env is on a GPU; torch modules otherwise
     fast_permutation: bool = True    # minibatch order from r6_permutation (a keyed bijection, one elementwise launch, part of
                                      # the epoch's graph) instead of torch.randperm (a sort: 0.22 ms per 2^20 rows); GPU only
+    fused_rollout: bool = True       # with the fused forward: the n_steps x (policy forward, env step, bootstrap value) of a rollout as
+                                     # ONE kernel launch (r6_rollout: state in registers throughout) where the env supports it
     graph_rollout: bool = True       # with the fused forward: a whole rollout (n_steps x (policy, env step, time-limit
                                      # bootstrap) + GAE) is recorded once into a HIP graph and replayed -- three launches
                                      # per step and no host work; the RNG counters advance through a device-side base
@@ -407,7 +409,10 @@ class PPO:
             self._grad_weight = float(self._bs / t[:, 1].sum())
             self._steps_per_epoch = int(t[:, 2].min())
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.buf_obs = torch.zeros((T, n, env.obs_dim), **f32)
+        # T + 1 observation rows: row t is what action t was computed from, row T the observation after the last step (the next
+        # rollout's row 0); the fused rollout kernel writes rows 1..T in one launch
+        self._buf_obs_ext = torch.zeros((T + 1, n, env.obs_dim), **f32)
+        self.buf_obs = self._buf_obs_ext[:T]
         self.buf_act = torch.zeros((T, n, 3), **f32)
         self.buf_logp = torch.zeros((T, n), **f32)
         self.buf_val = torch.zeros((T, n), **f32)
@@ -425,6 +430,7 @@ class PPO:
         # launch-only rollout (set up below when the fused forward exists): time-limit bootstrap folded into r6_gae,
         # env outputs written straight into the rollout buffer, the whole rollout replayed as a HIP graph
         self._time_limit, self._direct, self._in_kernel_bootstrap = False, None, False
+        self._one_launch_rollout = False
         self.buf_flags = self.buf_boot = None
         self._rollout_graph, self._rollouts = None, 0
         if cfg.fused_policy and self.device.type == "cuda":
@@ -446,6 +452,17 @@ class PPO:
                 # device-resident part of the step counters (graph replays): attached to the env only while the rollout's
                 # launches are issued or recorded -- an eager env.step() between rollouts must not add a stale base
                 self._step_base = torch.zeros((), dtype=torch.int64, device=self.device)
+                # the whole rollout as one launch (r6_rollout) where env and net are among its instances
+                p_ = getattr(env, "params", None)
+                self._one_launch_rollout = bool(cfg.fused_rollout and self._direct and hasattr(env, "rollout") and p_ is not None
+                                                and n <= self.ONE_LAUNCH_ROLLOUT_MAX_ENVS
+                                                and int(p_.n_substeps) == 1 and int(p_.integrator) in (0, 1)
+                                                and not (int(p_.integrator) == 0 and int(p_.shaping) == 1))
+
+    # r6_rollout keeps one 32-env tile per wave in registers for the whole rollout (built for few waves per SIMD): measured on
+    # MI355X, 64-step rollouts: 16 k envs 2.13 -> 0.46 ms, 65 k 2.27 -> 0.87, 262 k 3.84 -> 3.27, 2^20 envs 1.3x SLOWER than the
+    # three launches per step (scripts/rollout_fused_bench.py) -- large batches keep the launch sequence
+    ONE_LAUNCH_ROLLOUT_MAX_ENVS = 1 << 18
 
     def _all_reduce(self, t: torch.Tensor, op=None) -> torch.Tensor:
         """Sum (default) over ranks of a small host tensor: through the device for RCCL, on the host for gloo."""
@@ -473,7 +490,17 @@ class PPO:
         base = self._step_base
         env.set_step_base(base)
         try:
-            self._rollout_steps(env, T, base)
+            if self._one_launch_rollout:
+                self.buf_obs[0].copy_(self._obs)
+                env.rollout(self.fused, T, reward=self.buf_rew, done=self.buf_done, obs_seq=self._buf_obs_ext, raw_action=self.buf_act,
+                            value=self.buf_val, logp=self.buf_logp, flags=self.buf_flags if self._time_limit else None,
+                            boot_value=self.buf_boot if self._time_limit else None, policy_step_index=self._rollout_step + 1,
+                            policy_step_base=base)
+                self._rollout_step += T
+                if self._obs.data_ptr() != self._buf_obs_ext[T].data_ptr():
+                    self._obs.copy_(self._buf_obs_ext[T])
+            else:
+                self._rollout_steps(env, T, base)
         finally:
             env.set_step_base(None)
         bo = self._boot_out
@@ -517,7 +544,12 @@ class PPO:
     def collect_rollouts(self):
         env, cfg = self.env, self.cfg
         if self._obs is None:
-            self._obs = env.reset().clone()
+            first = env.reset()
+            if torch.is_tensor(first) and first.device == self.device:
+                self._obs = self._buf_obs_ext[cfg.n_steps]      # lives in the rollout buffer's extra row
+                self._obs.copy_(first)
+            else:
+                self._obs = first.clone()
         T = cfg.n_steps
         self._in_kernel_bootstrap = False
         if self.fused is not None and self._direct:

@@ -8,5 +8,5 @@ NAME=$1; shift
 OUT=$ROOT/rl_rocket_6dof_amd/csrc/variants
 mkdir -p $OUT
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fno-math-errno -fno-slp-vectorize -Wall -Wno-unused-function \
-  -Wl,-Bsymbolic "$@" $ROOT/rl_rocket_6dof_amd/csrc/r6_kernels.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_policy.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_ppo_update.hip -o $OUT/libr6dof_$NAME.so
+  -Wl,-Bsymbolic "$@" $ROOT/rl_rocket_6dof_amd/csrc/r6_kernels.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_policy.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_ppo_update.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_rollout.hip -o $OUT/libr6dof_$NAME.so
 echo $OUT/libr6dof_$NAME.so

@@ -1,0 +1,200 @@
+"""r6_rollout -- K closed-loop rollout steps in one launch -- against the launch sequence it replaces, BIT FOR BIT:
+per step  r6_policy_act (policy forward + Gaussian sample + clip)  ->  r6_step  ->  masked r6_policy_act (V(terminal observation)
+of the envs a TimeLimit truncated), i.e. SB3's collect_rollouts loop behind main_6DOF.py:136-139.  Compared: every observation,
+raw action, value, log-probability, reward, done mask, flag byte and bootstrap value of every step, the final simulator state,
+episode counters and episode statistics; both SB3 topologies, both obs widths, ragged tile, RK4 and Euler."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return json.loads(str(load_golden("g3_env_rollouts.npz")["config"]))
+
+
+def _make(torch, n, cfg, arch, shared, od, integrator, seed=5, **kw):
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.policy import FusedActorCritic
+    from rl_rocket_6dof_amd.ppo import ActorCritic
+
+    torch.manual_seed(11)
+    pol = ActorCritic(od, 3, arch, log_std_init=-0.7, shared_trunk=shared).to("cuda:0")
+    with torch.no_grad():                     # give the value head and the action head something to say
+        for m in pol.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(1.7)
+                m.bias.uniform_(-0.2, 0.2)
+    envs = [BatchedRocket6DOF(n, cfg, seed=seed, integrator=integrator, remove_mass=od == 13, record_flags=True, **kw) for _ in range(2)]
+    fused = FusedActorCritic(pol, seed=77, env_offset=0)
+    return envs, fused
+
+
+def _seed_low_altitude(envs):
+    """Part of the batch starts a few metres above the pad (golden G4's recorded pre-states): ground events, goal rewards and
+    in-kernel resets then fall inside a K of a few steps."""
+    G4 = load_golden("g4_ground_events.npz")
+    st = envs[0].get_state().cpu().numpy()
+    k = min(envs[0].num_envs // 2, len(G4["pre"]))
+    if k:
+        st[:k] = G4["pre"][len(G4["pre"]) - k:].astype(np.float32)
+    for e in envs:
+        e.set_state(st)
+
+
+def _sequence(torch, env, fused, K, step0):
+    """The unfused path: one launch per arrow, exactly what ppo.PPO._rollout_steps issues."""
+    n, od, dev = env.num_envs, env.obs_dim, env.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {"obs_seq": torch.zeros((K + 1, n, od), **f32), "raw_action": torch.zeros((K, n, 3), **f32), "value": torch.zeros((K, n), **f32),
+           "logp": torch.zeros((K, n), **f32), "reward": torch.zeros((K, n), **f32), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev),
+           "flags": torch.zeros((K, n), dtype=torch.uint8, device=dev), "boot_value": torch.zeros((K, n), **f32)}
+    out["obs_seq"][0].copy_(env.obs)
+    act = torch.zeros((n, 3), **f32)
+    scratch = (torch.zeros((n, 3), **f32), torch.zeros((n, 3), **f32), torch.zeros((n,), **f32))
+    for j in range(K):
+        fused(out["obs_seq"][j], step_index=step0 + j, out=(act, out["raw_action"][j], out["value"][j], out["logp"][j]))
+        env.step_into(act, obs=out["obs_seq"][j + 1], reward=out["reward"][j], done=out["done"][j], flags=out["flags"][j])
+        if env.max_episode_steps:
+            fused(env.final_obs, deterministic=True, step_index=0, out=(scratch[0], scratch[1], out["boot_value"][j], scratch[2]),
+                  row_flags=out["flags"][j], flag_mask=4)
+    return out
+
+
+def _fused(torch, env, fused, K, step0, base=None):
+    n, od, dev = env.num_envs, env.obs_dim, env.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {"obs_seq": torch.zeros((K + 1, n, od), **f32), "raw_action": torch.zeros((K, n, 3), **f32), "value": torch.zeros((K, n), **f32),
+           "logp": torch.zeros((K, n), **f32), "reward": torch.zeros((K, n), **f32), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev),
+           "flags": torch.zeros((K, n), dtype=torch.uint8, device=dev), "boot_value": torch.zeros((K, n), **f32)}
+    out["obs_seq"][0].copy_(env.obs)
+    env.rollout(fused, K, policy_step_index=step0, policy_step_base=base, **out)
+    return out
+
+
+CASES = [
+    # n, arch, shared, od, integrator, env kwargs
+    (1000, (64, 64), False, 13, "rk4", dict(clip_reward=(-1, 100), max_episode_steps=9)),
+    (4096, (128, 64), True, 13, "rk4", dict(clip_reward=(-1, 100), max_episode_steps=14)),
+    (780, (128, 64), True, 14, "rk4", dict()),       # (the sequence needs 16-byte aligned obs rows: n * obs_dim a multiple of 4)
+    (2048, (64, 64), False, 14, "euler", dict(max_episode_steps=11)),
+    (36, (64, 64), False, 13, "rk4", dict(max_episode_steps=5)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"n{c[0]}-{c[1][0]}x{c[1][1]}{'s' if c[2] else ''}-od{c[3]}-{c[4]}" for c in CASES])
+def test_fused_rollout_equals_the_launch_sequence(cfg, case):
+    import torch
+
+    n, arch, shared, od, integ, kw = case
+    (ea, eb), fused = _make(torch, n, cfg, arch, shared, od, integ, **kw)
+    for e in (ea, eb):
+        e.reset()
+    _seed_low_altitude((ea, eb))
+    K = 24
+    ref = _sequence(torch, ea, fused, K, step0=1000)
+    got = _fused(torch, eb, fused, K, step0=1000)
+    torch.cuda.synchronize()
+    n_done, n_trunc = int(ref["done"].sum()), int((ref["flags"] & 4).ne(0).sum())
+    assert n_done > n // 4, "the case must exercise episode ends and in-kernel resets"
+    for name in ("raw_action", "value", "logp", "reward", "done", "flags"):
+        assert torch.equal(ref[name], got[name]), f"{name} differs (first step: {int((ref[name] != got[name]).flatten(1).any(1).float().argmax())})"
+    assert torch.equal(ref["obs_seq"][1:], got["obs_seq"][1:]), "observations differ"
+    if kw.get("max_episode_steps"):
+        m = (ref["flags"] & 4).ne(0)
+        assert n_trunc > 0 and torch.equal(ref["boot_value"][m], got["boot_value"][m]), "V(terminal observation) of truncated envs differs"
+    assert torch.equal(ea.state, eb.state) and torch.equal(ea.epconst, eb.epconst), "final simulator state differs"
+    assert torch.equal(ref["obs_seq"][K], eb.obs), "env.obs after the rollout = the observation after the last step"
+    assert ea._step_count == eb._step_count
+    if ea.ep_step is not None:
+        assert torch.equal(ea.ep_step, eb.ep_step) and torch.equal(ea.ep_return, eb.ep_return)
+        assert torch.equal(ea.stats.sum(0), eb.stats.sum(0)), "episode statistics differ"
+        assert float(ea.stats.sum(0)[0]) == n_done
+    print(f"[fused rollout {case[:5]}] {K} steps, {n_done} episode ends, {n_trunc} truncations: identical")
+
+
+def test_fused_rollout_continues_and_replays_from_a_graph(cfg):
+    """Two consecutive fused rollouts equal one sequence of 2 K steps, and a rollout recorded into a HIP graph with device-side
+    step bases replays to the same numbers (the bases continue both RNG streams)."""
+    import torch
+
+    n, K = 2048, 12
+    (ea, eb), fused = _make(torch, n, cfg, (128, 64), True, 13, "rk4", clip_reward=(-1, 100), max_episode_steps=10)
+    for e in (ea, eb):
+        e.reset()
+    ref = _sequence(torch, ea, fused, 2 * K, step0=1)
+    base = torch.zeros((), dtype=torch.int64, device=eb.device)
+    eb.set_step_base(base)
+    first = _fused(torch, eb, fused, K, step0=1, base=base)
+    torch.cuda.synchronize()
+    # record the same launch (host counters as at the first rollout) and replay it with both bases moved on by K
+    c0 = eb._step_count - K
+    out = {k: torch.zeros_like(v) for k, v in first.items()}
+    out["obs_seq"][0].copy_(eb.obs)
+    side = torch.cuda.Stream(device=eb.device)
+    eb._step_count = c0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        eb.rollout(fused, K, policy_step_index=1, policy_step_base=base, **out)
+    eb._step_count = c0 + K
+    base.fill_(K)
+    g.replay()
+    torch.cuda.synchronize()
+    eb._step_count += K
+    for name in ("raw_action", "value", "logp", "reward", "done", "flags"):
+        assert torch.equal(ref[name][:K], first[name]), name
+        assert torch.equal(ref[name][K:], out[name]), f"replayed {name}"
+    assert torch.equal(ref["obs_seq"][K + 1:], out["obs_seq"][1:])
+    assert torch.equal(ea.state, eb.state)
+
+
+def test_rollout_rejects_what_it_does_not_support(cfg):
+    import torch
+
+    from rl_rocket_6dof_amd import _lib
+
+    (ea, _), fused = _make(torch, 64, cfg, (64, 64), False, 13, "rk4")
+    ea.reset()
+    K, n, dev = 4, 64, ea.device
+    rew, done = torch.zeros((K, n), device=dev), torch.zeros((K, n), dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        ea.rollout(fused, K, reward=rew[:, :32], done=done)
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    e45 = BatchedRocket6DOF(n, cfg, integrator="rk45", remove_mass=True)
+    e45.reset()
+    with pytest.raises(_lib.R6Error):
+        e45.rollout(fused, K, reward=rew, done=done)
+
+
+@pytest.mark.parametrize("max_steps,shared", [(0, False), (9, True)])
+def test_ppo_one_launch_rollout_equals_the_three_launch_rollout(cfg, max_steps, shared):
+    """ppo.PPO with fused_rollout on / off, same seeds: every rollout buffer, the advantages and the env state of three consecutive
+    rollouts (the first eager, the others replayed from a HIP graph) agree bit for bit."""
+    import torch
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+    runs = []
+    for one_launch in (False, True):
+        kw = dict(seed=11, remove_mass=True, clip_reward=(-1, 100))
+        if max_steps:
+            kw.update(record_flags=True, max_episode_steps=max_steps)
+        env = BatchedRocket6DOF(4096, cfg, **kw)
+        algo = PPO(env, PPOConfig(n_steps=24, batch_size=1 << 14, net_arch=(128, 64), shared_trunk=shared, seed=3, fused_rollout=one_launch))
+        assert algo.fused is not None and algo._one_launch_rollout == one_launch
+        snaps = []
+        for _ in range(3):
+            algo.collect_rollouts()
+            snaps.append([t.clone() for t in (algo.buf_obs, algo.buf_act, algo.buf_rew, algo.buf_done, algo.buf_val, algo.buf_logp,
+                                              algo.adv, algo.ret, algo._obs, env.state, env.stats.sum(0))])
+        assert algo._rollout_graph is not None and env._step_count == 72
+        runs.append(snaps)
+    for k, (a, b) in enumerate(zip(*runs)):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (k, i)
