@@ -58,6 +58,10 @@ constexpr int kWaves = kBlock / 64;
 #ifndef R6_RESET_QUEUE
 #define R6_RESET_QUEUE 2048
 #endif
+#define R6_K_DIRECT_OBS_INTERNAL 0x4000     // R6StepK.flags bit set by the launcher (not part of the ABI): obs stored from registers
+#ifndef R6_K_DIRECT_MAX_TILES
+#define R6_K_DIRECT_MAX_TILES 1024          // r6_step_k: up to one 64-env tile per SIMD the direct form is used (65 536 envs: 3.47 -> 3.25 us per step at K = 16; at 262 144 envs it is 35 % slower than the transposing form)
+#endif
 #ifndef R6_EARLY_LOAD
 #define R6_EARLY_LOAD 1         // A/B switch (RK4 / RK45 instances): rotated tile loop, first tile requested before the set-up barrier
 #endif
@@ -762,6 +766,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
     const int K = sk.k;
     const bool last_only = (sk.flags & R6_K_LAST_ONLY) != 0;
+    const bool direct_obs = (sk.flags & R6_K_DIRECT_OBS_INTERNAL) != 0;
 
 #ifdef R6_TRACE_K   // dev build (scripts/stepk_trace.py): per-wave 100 MHz stamps, written to the rows of `stats`
     const uint64_t tk0 = wall_clock64();
@@ -895,11 +900,22 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                 if (b.nfev) uniform_ptr(b.nfev + ((int64_t)k * sk.nfev_stride + e0))[lane] = (uint8_t)(nfev > 255 ? 255 : nfev);
             }
             // observation (env:503-504): registers -> LDS row-major tile
+            // Two forms of the AoS edge (wave-uniform choice of the launcher, R6_K_DIRECT_OBS).  Transposing: through the wave's
+            // LDS tile, stored as contiguous 16 B per lane -- what a bandwidth-bound launch wants.  Direct: every lane stores its
+            // own row as dwords straight from registers -- 14 scattered store instructions instead of 4 wide ones, but no LDS
+            // write -> read round trip and no wave-level syncs in the step's critical path, which is what counts when a SIMD
+            // holds a single wave (BASELINE configs[1]: 1024 tiles on 1024 SIMDs; per-wave stamps put the two LDS phases at
+            // 1.5 k of a step's 4.9 k cycles).
+            float ob[OD];
 #pragma unroll
             for (int j = 0; j < kDyn; ++j) {
-                if (j < OD) tile[lane * OD + j] = y[j] * lds_inv_norm[j];
+                if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
             }
-            if (OD == 14) tile[lane * OD + (OD - 1)] = mass * lds_inv_norm[13];
+            if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
+            if (!direct_obs) {
+#pragma unroll
+                for (int j = 0; j < OD; ++j) tile[lane * OD + j] = ob[j];
+            }
 
             // ---- finished episodes: terminal outputs, statistics, and Rocket6DOF.reset (env:180-199) in the lane -----
 #ifdef R6_TRACE_K
@@ -915,7 +931,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                         if (b.final_obs) {
                             float* fo = b.final_obs + ((int64_t)k * sk.final_obs_stride + i * OD);
 #pragma unroll
-                            for (int j = 0; j < OD; ++j) fo[j] = tile[lane * OD + j];
+                            for (int j = 0; j < OD; ++j) fo[j] = ob[j];
                         }
                         if (b.fin_return) b.fin_return[(int64_t)k * sk.fin_stride + i] = ep_ret;
                         if (b.fin_length) b.fin_length[(int64_t)k * sk.fin_stride + i] = ep_step;
@@ -944,7 +960,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                             ep_step = 0u;
                             ep_ret = 0.0f;
 #pragma unroll
-                            for (int q = 0; q < OD; ++q) tile[lane * OD + q] = ic[q] * lds_inv_norm[q];   // the fresh episode's first observation
+                            for (int q = 0; q < OD; ++q) ob[q] = ic[q] * lds_inv_norm[q];   // the fresh episode's first observation
+                            if (!direct_obs) {
+#pragma unroll
+                                for (int q = 0; q < OD; ++q) tile[lane * OD + q] = ob[q];
+                            }
                         }
                     } while (fin != 0ull);
                 }
@@ -952,6 +972,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
 
             // ---- LDS tile -> contiguous 16 B-per-lane stores of this step's (64, OD) observation block -----------------
             TKSTAMP(ts3);
+            if (direct_obs) {
+                if (emit && live) {
+                    float* dst = b.obs + ((int64_t)k * sk.obs_stride + i * OD);
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) dst[j] = ob[j];
+                }
+            } else {
             wave_lds_sync();
             if (emit) {
                 const gptr<float> dst = uniform_ptr(b.obs + ((int64_t)k * sk.obs_stride + e0 * OD));
@@ -967,6 +994,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
                 }
             }
             wave_lds_sync();
+            }
 #ifdef R6_TRACE_K
             {
                 TKSTAMP(ts4);
@@ -1385,7 +1413,12 @@ void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk
     int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
     const int cap = resident_blocks(kernel, slot);
     if (blocks > cap) blocks = cap;   // persistent waves: a tile's K steps are serial, tiles are spread over the resident grid
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, sk, seed, step, off);
+    // few waves per SIMD: the observation leaves straight from registers (see step_k_kernel).  R6_K_DIRECT=0|1 overrides.
+    static const int direct_env = [] { const char* e = std::getenv("R6_K_DIRECT"); return e ? std::atoi(e) : -1; }();
+    R6StepK skl = sk;
+    const bool direct = direct_env >= 0 ? direct_env != 0 : n_tiles <= R6_K_DIRECT_MAX_TILES;
+    skl.flags = (sk.flags & ~R6_K_DIRECT_OBS_INTERNAL) | (direct ? R6_K_DIRECT_OBS_INTERNAL : 0);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, skl, seed, step, off);
 }
 
 template <int INTEG, int SHAPING>
