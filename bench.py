@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_RAW = 189
 BYTES_WRAPPED = 201            # obs 13 floats (-4 B), ep_step r+w (+8), ep_return r+w (+8)
-TRAFFIC_PROFILE = os.path.join("profiles", "r2_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r3_pmc_traffic.json")
 
 
 def bytes_per_env_step(variant: str, k: int = 1, obs_dim: int = 14) -> float:
@@ -253,7 +253,7 @@ def traffic_from_profile(variant: str, integrator: str, n: int, k: int):
         return None, None
 
 
-VALU_PROFILE = os.path.join("profiles", "r2_pmc_valu.json")
+VALU_PROFILE = os.path.join("profiles", "r3_pmc_valu.json")
 SIMDS, ENGINE_CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
 
 
@@ -271,7 +271,11 @@ def valu_from_profile(variant: str, integrator: str, n: int, k: int, kernel_ms: 
                 "instructions_per_64_env_tile": prof["derived"]["valu_instructions_per_64_env_tile"],
                 "source": f"{VALU_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); engine clock "
                           f"assumed at its {ENGINE_CLOCK_HZ / 1e9:.1f} GHz peak",
-                "note": "the step kernel is co-bound: VALU issue and HBM are each busy for about two thirds of a launch"}
+                "busy_frac_at_2.1GHz": 4.0 * active / SIMDS / (2.1e9 * kernel_ms * 1e-3),
+                "note": "the step kernel is VALU-issue bound at the clock the chip actually holds under it: a clock probe (s_memtime / "
+                        "s_memrealtime per workgroup, profiles/r3_experiments.json) reads 2.03-2.21 GHz during the RK4 step against 2.33-2.37 "
+                        "GHz during the Euler step, so the issue share is 0.70-0.76 of a launch whose first ~4 us (every wave waiting for "
+                        "its first tile) cannot issue anything; HBM is busy for about two thirds of the launch"}
     except Exception:
         return None
 

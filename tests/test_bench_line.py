@@ -104,7 +104,7 @@ def test_two_rank_line_over_gloo():
 
 
 def test_valu_object_from_the_committed_profile():
-    """bench.py's `valu` object (the step kernel's second limiter): derived from profiles/r2_pmc_valu.json and the run's
+    """bench.py's `valu` object (the step kernel's second limiter): derived from profiles/r3_pmc_valu.json and the run's
     kernel time, only for the profiled workload, and labelled as a static file."""
     import bench
 
