@@ -59,6 +59,60 @@ constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// The layer products whose B operand is an activation block in accumulator layout -- forward layers 1 and 2 (160 full-size MFMAs of a
+// tile), the delta1 chains (128) -- can run as v_mfma_f32_32x32x16_f16 on f16 hi + lo splits of both operands (three or four products
+// per K-step of 16, fp32 accumulation; the scheme of r6_policy.hip) instead of v_mfma_f32_32x32x2_f32.  Measured on MI355X
+// (scripts/ppo_grad_ab.py, 65 536 samples, gradient + reduce): exact fp32 everywhere 63.4 us; delta1 chains in f16 (R6U_F16_BWD, the
+// default): see DESIGN.md section 7; forward AND delta1 in f16: 52.2-53.1 us -- but a two-term f16 split keeps 22 of an operand's 24
+// bits, and the forward's error reaches every gradient through the loss: the value head's bias gradient, a sum over the samples that
+// cancels to a few per cent of its terms, then misses the autograd test's 2e-5 by 1.4x (9.7e-8 against 7.0e-8 absolute, 300
+// samples, two (64, 64) MLPs; all other 17 parametrisations pass).  So the forward stays exact by default (R6U_F16_FWD=1 is the
+// measured-and-not-shipped variant); the delta operands, scaled per tile by a power of two, only feed dW1 / db1, which tolerate it.
+// The weight-gradient products (contraction over the samples) stay exact fp32 in every mode.
+#ifndef R6U_F16_FWD
+#define R6U_F16_FWD 0
+#endif
+#ifndef R6U_F16_BWD
+#define R6U_F16_BWD 1
+#endif
+#define R6U_F16_ANY (R6U_F16_FWD || R6U_F16_BWD)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+struct Split {
+    h8 hi, lo;
+};
+__device__ __forceinline__ void split2(float a, float b, h2& hi, h2& lo) {
+    hi = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+}
+__device__ __forceinline__ Split split8(const float (&x)[8]) {
+    Split s;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        h2 hi, lo;
+        split2(x[j], x[j + 1], hi, lo);
+        s.hi[j] = hi[0];
+        s.hi[j + 1] = hi[1];
+        s.lo[j] = lo[0];
+        s.lo[j + 1] = lo[1];
+    }
+    return s;
+}
+// acc += A * B with all four partial products: the forward pass uses this form -- everything downstream (the loss gradient g, and
+// with it every parameter gradient, among them bias gradients that are cancelled sums over the samples) inherits the forward's
+// error, and lo * lo (2^-22 of a product) is the largest term the three-product form drops; a fourth f16 MFMA costs 32 cycles
+__device__ __forceinline__ f32x16 mfma4(const h8& ah, const h8& al, const Split& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
+}
+// acc += A * B to fp32 accuracy: three half-precision products (lo * lo is below fp32 resolution)
+__device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.lo, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
+}
 
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -101,10 +155,32 @@ template <int NETS, int H1, int H2>
 struct Image {
     static constexpr int kP1 = (NETS == 2) ? 8 : 12;   // floats per lane of the layer-1 image (8 used); 12 is the conflict-free pitch, two
                                                        // nets trade it (2 reads per chain, 2-way conflicts) for 4 KB of LDS
+    // f16 images (offsets and sizes still in floats = pairs of halves): per chain and K-step of 16 one fragment of 64 lanes x 8
+    // halves (one ds_read_b128 per lane), a hi copy followed by a lo copy:
+    //   w1   [chain = net*B1 + blk][hi|lo][64][8]                  lane l, elem j: W1[blk*32 + (l&31)][k = 8(l>>5) + j]; k == OD carries b1
+    //   w2   [chain = (net*B2 + mb)*B1 + b][step s][hi|lo][64][8]   W2[mb*32 + (l&31)][32b + row(8s + j, l>>5)]
+    //   w2t  [chain = (net*B1 + ib)*B2 + c][step s][hi|lo][64][8]   W2[32c + row(8s + j, l>>5)][ib*32 + (l&31)]
+    static constexpr int kFrag = 64 * 8 / 2;           // floats per fragment copy
+#if R6U_F16_FWD
+    static constexpr int oW1 = 0, kW1 = NETS * (H1 / 32) * 2 * kFrag;
+    static constexpr int oW2 = oW1 + kW1, kW2 = NETS * (H2 / 32) * (H1 / 32) * 2 * 2 * kFrag;
+#else
     static constexpr int oW1 = 0, kW1 = NETS * (H1 / 32) * 64 * kP1;
     static constexpr int oW2 = oW1 + kW1, kW2 = NETS * (H2 / 32) * (H1 / 32) * 64 * kP2;
+#endif
     static constexpr int oW2T = oW2 + kW2;
-    static constexpr int oB2 = oW2T + kW2, kB2 = NETS * (H2 / 32) * 2 * 16;
+#if R6U_F16_BWD
+    static constexpr int kW2T = NETS * (H2 / 32) * (H1 / 32) * 2 * 2 * kFrag;
+#else
+    static constexpr int kW2T = NETS * (H2 / 32) * (H1 / 32) * 64 * kP2;
+#endif
+#if R6U_F16_ANY
+    // the 11 running sums of a sample-owning lane (lane half 0): [k][wave][32] -- the f32 images' padding held them in round 2
+    static constexpr int oStat = oW2T + kW2T, kStat = 11 * kWaves * 32;
+    static constexpr int oB2 = oStat + kStat, kB2 = NETS * (H2 / 32) * 2 * 16;
+#else
+    static constexpr int oB2 = oW2T + kW2T, kB2 = NETS * (H2 / 32) * 2 * 16;
+#endif
     static constexpr int oW3 = oB2 + kB2, kW3 = NETS * 2 * (H2 / 32) * 16 * 4;
     static constexpr int kImage = oW3 + kW3;
     // per-wave staging (transposed tiles): a2 / delta2 [H2][kPitch], one 32-row block [32][kPitch], x [16][kPitch], g [4][kPitch]
@@ -164,6 +240,25 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     const uint64_t ts0 = wall_clock64();
 #endif
     // ---- stage the weight images -------------------------------------------------------------------------------------
+#if R6U_F16_ANY
+    _Float16* ldsh = reinterpret_cast<_Float16*>(lds);
+    auto put_split = [&](int frag_float_off, int e, float v) __attribute__((always_inline)) {   // e = lane * 8 + elem within the fragment
+        const _Float16 hi = (_Float16)v;
+        ldsh[2 * frag_float_off + e] = hi;
+        ldsh[2 * (frag_float_off + Im::kFrag) + e] = (_Float16)(v - (float)hi);
+    };
+#endif
+#if R6U_F16_FWD
+#pragma unroll 8
+    for (int e = tid; e < NETS * B1 * 64 * 8; e += kBlock) {
+        const int j = e & 7, l = (e >> 3) & 63, chain = e >> 9;   // chain = net * B1 + blk
+        const int ni = chain / B1, blk = chain % B1;
+        const int k = 8 * (l >> 5) + j, m = blk * 32 + (l & 31);
+        const float* w = ni ? net.vf_w1 : net.pi_w1;
+        const float* b = ni ? net.vf_b1 : net.pi_b1;
+        put_split(Im::oW1 + chain * 2 * Im::kFrag, e & 511, (k < OD) ? w[m * OD + k] : ((k == OD) ? b[m] : 0.0f));
+    }
+#else
 #pragma unroll 8
     for (int e = tid; e < NETS * B1 * 64 * 8; e += kBlock) {
         const int s = e & 7, l = (e >> 3) & 63, chain = e >> 9;   // chain = net * B1 + blk
@@ -173,18 +268,30 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         const float* b = ni ? net.vf_b1 : net.pi_b1;
         lds[Im::oW1 + (chain * 64 + l) * kP1 + s] = (k < OD) ? w[m * OD + k] : ((k == OD) ? b[m] : 0.0f);
     }
+#endif
 #pragma unroll 8   // independent gathers from L2: eight in flight per thread instead of one round trip per element
     for (int e = tid; e < NETS * B2 * B1 * 64 * 16; e += kBlock) {
-        const int r = e & 15, l = (e >> 4) & 63, rest = e >> 10;
+        // f32 layout: e = (chain * 64 + l) * 16 + r;  f16 layout: e = ((chain * 2 + step) * 64 + l) * 8 + j, r = 8 step + j
+        const int rest = e >> 10;                      // chain
         const int ni = rest / (B2 * B1), loc = rest % (B2 * B1);
         const float* w = ni ? net.vf_w2 : net.pi_w2;
+        const int r32 = e & 15, l32 = (e >> 4) & 63;
+        const int j16 = e & 7, l16 = (e >> 3) & 63, st16 = (e >> 9) & 1, r16 = 8 * st16 + j16;
         {   // w2: chain (net * B2 + mb) * B1 + b
             const int b = loc % B1, mb = loc / B1;
-            lds[Im::oW2 + (rest * 64 + l) * kP2 + r] = w[(mb * 32 + (l & 31)) * H1 + 32 * b + rowmap(r, l >> 5)];
+#if R6U_F16_FWD
+            put_split(Im::oW2 + (rest * 2 + st16) * 2 * Im::kFrag, e & 511, w[(mb * 32 + (l16 & 31)) * H1 + 32 * b + rowmap(r16, l16 >> 5)]);
+#else
+            lds[Im::oW2 + (rest * 64 + l32) * kP2 + r32] = w[(mb * 32 + (l32 & 31)) * H1 + 32 * b + rowmap(r32, l32 >> 5)];
+#endif
         }
         {   // w2t: chain (net * B1 + ib) * B2 + c
             const int c = loc % B2, ib = loc / B2;
-            lds[Im::oW2T + (rest * 64 + l) * kP2 + r] = w[(32 * c + rowmap(r, l >> 5)) * H1 + ib * 32 + (l & 31)];
+#if R6U_F16_BWD
+            put_split(Im::oW2T + (rest * 2 + st16) * 2 * Im::kFrag, e & 511, w[(32 * c + rowmap(r16, l16 >> 5)) * H1 + ib * 32 + (l16 & 31)]);
+#else
+            lds[Im::oW2T + (rest * 64 + l32) * kP2 + r32] = w[(32 * c + rowmap(r32, l32 >> 5)) * H1 + ib * 32 + (l32 & 31)];
+#endif
         }
     }
     for (int e = tid; e < Im::kB2; e += kBlock) {   // ((net * B2 + mb) * 2 + h) * 16 + r
@@ -240,10 +347,16 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     // The 11 running sums of a lane (db3[4], dlog_std[3], pg, v, clip_frac, kl) live in LDS, in the padding of the w2 image
     // (pitch kP2 = 20, 16 used): lane l of wave w owns float 16 + w of its row in chain k.  In registers they were the
     // first thing the allocator parked in scratch (11 reload-add-spill round trips per tile).
+#if R6U_F16_ANY
+    constexpr int kStatStride = kWaves * 32;                 // f16 images have no padding: the sums have an area of their own, one slot per sample-owning lane
+    int o_stat = Im::oStat + wave * 32 + col;
+#else
+    constexpr int kStatStride = 64 * kP2;
     static_assert(kP2 - 16 >= kWaves && 2 * NETS * B2 * B1 >= 11 && Im::oW2T == Im::oW2 + Im::kW2, "stat slots fit into the padding of the w2 and w2t images (contiguous)");
     int o_stat = Im::oW2 + lane * kP2 + 16 + wave;
+#endif
 #pragma unroll
-    for (int k = 0; k < 11; ++k) lds[o_stat + k * 64 * kP2] = 0.0f;
+    for (int k = 0; k < 11; ++k) lds[o_stat + k * kStatStride] = 0.0f;
 
     // ---- accumulators of the launch -----------------------------------------------------------------------------------
     f32x16 acc[NETS * B2 * B1];                              // dW2 [net][mb][ib]
@@ -283,7 +396,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     auto fetch_data = [&](int r, float (&x)[8], float (&sv)[6]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int k = 2 * s + h;
+            const int k = R6U_F16_FWD ? s + 8 * h : 2 * s + h;   // the K layout of the layer-1 MFMA: 8 consecutive features per lane half (f16, K = 16) or interleaved (f32, K = 2 per step)
             x[s] = 0.0f;
             if (r >= 0) {
                 if (k < OD) x[s] = a.obs[(int64_t)r * OD + k];
@@ -329,13 +442,63 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         float* stat_base = lds + o_stat;
         wave_sync();   // the previous tile's readers of the staging area are done
 #pragma unroll
-        for (int s = 0; s < 8; ++s) tw4_base[Im::sX + (2 * s - 3 * h) * kPitch] = xk[s];   // row 2s + h (the base sits at row 4h)
+        for (int s = 0; s < 8; ++s) tw4_base[Im::sX + (R6U_F16_FWD ? s + 4 * h : 2 * s - 3 * h) * kPitch] = xk[s];   // row k of this lane's feature (the base sits at row 4h)
         const float act0 = sv[0], act1 = sv[1], act2 = sv[2], olp = sv[3], advv = sv[4], retv = sv[5];
 #ifdef R6U_STAMPS
         R6U_MARK(0);
 #endif
         // ---- forward: one net after the other (the two MLPs share nothing but x) ------------------------------------------
         f32x16 a1[NETS][B1], a2[NETS][B2];
+#if R6U_F16_ANY
+        const h8* frag = reinterpret_cast<const h8*>(lds);          // fragment copies are 64 lanes x 16 bytes: index = float offset / 4 + lane
+#endif
+#if R6U_F16_FWD
+        const Split xs = split8(xk);
+#pragma unroll
+        for (int ni = 0; ni < NETS; ++ni) {
+#pragma unroll
+            for (int blk = 0; blk < B1; ++blk) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+                const int f = (Im::oW1 + (ni * B1 + blk) * 2 * Im::kFrag) / 4 + lane;
+                z = mfma4(frag[f], frag[f + Im::kFrag / 4], xs, z);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[ni][blk][r] = tanh_fast(z[r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x16 z2[B2];
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) {
+                float zi[16];
+                ldv<16>(b2_base + (ni * B2 + mb) * 32, zi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z2[mb][r] = zi[r];
+            }
+#pragma unroll
+            for (int b = 0; b < B1; ++b) {
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = a1[ni][b][sk * 8 + j];
+                    const Split bs = split8(v);
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) {
+                        const int f = (Im::oW2 + ((((ni * B2 + mb) * B1 + b) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
+                        z2[mb] = mfma4(frag[f], frag[f + Im::kFrag / 4], bs, z2[mb]);
+                    }
+                    asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a2[ni][mb][r] = tanh_fast(z2[mb][r]);
+            }
+        }
+#else
 #pragma unroll
         for (int ni = 0; ni < NETS; ++ni) {
 #pragma unroll
@@ -377,6 +540,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 }
             }
         }
+#endif
         R6U_MARK(1);   // forward
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -420,9 +584,9 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                                        -fminf(s1, s2), ve * ve, (fabsf(ratio - 1.0f) > a.clip) ? 1.0f : 0.0f, (ratio - 1.0f) - dl};
                 float cur[11];
 #pragma unroll
-                for (int k = 0; k < 11; ++k) cur[k] = stat_base[k * 64 * kP2];
+                for (int k = 0; k < 11; ++k) cur[k] = stat_base[k * kStatStride];
 #pragma unroll
-                for (int k = 0; k < 11; ++k) stat_base[k * 64 * kP2] = cur[k] + add[k];
+                for (int k = 0; k < 11; ++k) stat_base[k * kStatStride] = cur[k] + add[k];
             }
         }
 
@@ -488,6 +652,37 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
             R6U_MARK(4);   // delta2 + db2
             // ---- per 32-feature block of layer 1: dW2 (needs a1), delta1 (needs a1), dW1 (needs delta1 and x) -------------------
+#if R6U_F16_BWD
+            // delta2 as the f16 B operand of the delta1 chains: gradients are tiny (g carries 1 / n) and of any magnitude, so the
+            // tile is scaled by a power of two first -- exact -- such that its largest entry sits in [2^13, 2^14): far from f16's
+            // 65504, and every entry down to 2^-16 of the largest one still splits into a normal hi and a normal-or-exact lo
+            Split d2s[B2][2];
+            float d2_unscale;
+            {
+                float m = 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(d2[mb][r]));
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+                int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;     // floor(log2 m); -127 for zero / denormal
+                if (e < -100) e = -100;                                      // nothing to scale: keep the factor finite
+                const float scale = __uint_as_float((uint32_t)(127 + 13 - e) << 23);
+                d2_unscale = __uint_as_float((uint32_t)(127 - 13 + e) << 23);
+#pragma unroll
+                for (int c = 0; c < B2; ++c) {
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = d2[c][sk * 8 + j] * scale;
+                        d2s[c][sk] = split8(v);
+                    }
+                }
+            }
+#endif
             float dT[2][16], bxc[8];   // delta2^T rows and x's row are the same for every block: fetched once per net and tile
             ldv<16>(tr_base + Im::sT2, dT[0]);
             ldv<16>(tr_base + Im::sT2 + 32 * kPitch, dT[1]);
@@ -500,11 +695,15 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 wave_sync();
                 // dW2[f2][i] += sum_s delta2[f2][s] a1[i][s]
                 // Each chain's operands are fetched while the chain before it runs (static_assert: B2 == 2).
+#if !R6U_F16_BWD
                 float op[2][16];
+#endif
                 {
                     float ba[16];
                     ldv<16>(tr_base + Im::sBlk, ba);
+#if !R6U_F16_BWD
                     ldv<16>(&lds[Im::oW2T + (((ni * B1 + ib) * B2 + 0) * 64 + lane) * kP2], op[0]);
+#endif
 #pragma unroll
                     for (int s = 0; s < 16; ++s) acc[iW2(ni, 0, ib)] = mfma(dT[0][s], ba[s], acc[iW2(ni, 0, ib)]);
                     R6U_CHAIN_FENCE();
@@ -517,6 +716,19 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 f32x16 d1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+#if R6U_F16_BWD
+#pragma unroll
+                for (int c = 0; c < B2; ++c) {
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk) {
+                        const int f = (Im::oW2T + ((((ni * B1 + ib) * B2 + c) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
+                        d1 = mfma3(frag[f], frag[f + Im::kFrag / 4], d2s[c][sk], d1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] = (d1[r] * d2_unscale) * fmaf(-a1[ni][ib][r], a1[ni][ib][r], 1.0f);
+#else
                 ldv<16>(&lds[Im::oW2T + (((ni * B1 + ib) * B2 + 1) * 64 + lane) * kP2], op[1]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1 = mfma(op[0][r], d2[0][r], d1);
@@ -526,6 +738,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 R6U_CHAIN_FENCE();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1[r] *= fmaf(-a1[ni][ib][r], a1[ni][ib][r], 1.0f);
+#endif
                 R6U_MARK(6 + 3 * ib);   // B2
                 wave_sync();   // dW2's reads of the a1 block are done: delta1 takes its place
 #pragma unroll
@@ -556,7 +769,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #endif
     float sc[11];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) sc[k] = lds[o_stat + k * 64 * kP2];
+    for (int k = 0; k < 11; ++k) sc[k] = (R6U_F16_ANY && h != 0) ? 0.0f : lds[o_stat + k * kStatStride];   // (own area: the two halves of an env share a slot)
     __syncthreads();
     float* reds = lds;                             // [kWaves][kScalars]: the weight images are not needed any more
     float* out = partial + (int64_t)blockIdx.x * kPartial;
