@@ -203,6 +203,17 @@ __device__ __forceinline__ void rhs_quat(const float (&y)[kDyn], float (&dq)[4])
     dq[3] = 0.5f * fmaf(wz, q0, fmaf(wy, q1, -wx * q2));
 }
 
+// The same without the factor 1/2: (2 qdot)[0] is the NEGATIVE of d2[0] (the caller folds -1/2 and 1/2 into its step weights --
+// scaling by a power of two is exact, so  w * (0.5 * X) == (0.5 * w) * X  bit for bit, and four multiplies per RK4 stage go away).
+__device__ __forceinline__ void rhs_quat_x2(const float (&y)[kDyn], float (&d2)[4]) {
+    const float q0 = y[6], q1 = y[7], q2 = y[8], q3 = y[9];
+    const float wx = y[10], wy = y[11], wz = y[12];
+    d2[0] = fmaf(wx, q1, fmaf(wy, q2, wz * q3));            // = -2 dq0
+    d2[1] = fmaf(wx, q0, fmaf(wz, q2, -wy * q3));           // =  2 dq1
+    d2[2] = fmaf(wy, q0, fmaf(-wz, q1, wx * q3));           // =  2 dq2
+    d2[3] = fmaf(wz, q0, fmaf(wy, q1, -wx * q2));           // =  2 dq3
+}
+
 // sim:106-143 -- derivative of the 13 dynamic components; `im` = 1 / mass at this time.
 __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Control& c, const Inertia& J,
                                       float (&dy)[kDyn]) {
@@ -260,12 +271,32 @@ __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, co
             const float tm = (s == 0) ? 0.0f : ((s == 3) ? h : hh);      // stage time offset
             const float w = (s == 0 || s == 3) ? h6 : 2.0f * h6;         // quadrature weight * h
             const float an = (s == 2) ? h : hh;                          // next stage's step
-            rhs13(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, kend);
+            {   // rhs13 with the quaternion rows left at twice their value (rhs_quat_x2): the 1/2 sits in wq / aq below
+                float dv[3], dw[2], d2[4];
+                rhs_dyn(yt, frcp(fmaf(-c.mdot, tm, mass)), c, J, dv, dw);
+                rhs_quat_x2(yt, d2);
+                kend[0] = yt[3];
+                kend[1] = yt[4];
+                kend[2] = yt[5];
+                kend[3] = dv[0];
+                kend[4] = dv[1];
+                kend[5] = dv[2];
+                kend[6] = d2[0];
+                kend[7] = d2[1];
+                kend[8] = d2[2];
+                kend[9] = d2[3];
+                kend[10] = 0.0f;
+                kend[11] = dw[0];
+                kend[12] = dw[1];
+            }
+            const float wq = 0.5f * w, aq = 0.5f * an;
 #pragma unroll
             for (int i = 0; i < kDyn; ++i) {
                 if (i == 10) continue;   // d(omega_x)/dt == 0 exactly (rhs13): omega_x stays y0[10]
-                y1[i] = fmaf(w, kend[i], y1[i]);
-                yt[i] = fmaf(an, kend[i], y0[i]);
+                const float wi = (i == 6) ? -wq : ((i >= 7 && i <= 9) ? wq : w);
+                const float ai = (i == 6) ? -aq : ((i >= 7 && i <= 9) ? aq : an);
+                y1[i] = fmaf(wi, kend[i], y1[i]);
+                yt[i] = fmaf(ai, kend[i], y0[i]);
             }
         }
     }
@@ -600,6 +631,10 @@ __device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, con
 // minimum) does the iteration restart from 0 (0.1 % of states).  Eight unrolled, branch-free Newton
 // steps cover 99 % of the lanes; a wave-uniform tail loop finishes the rest.  fp32 iterations, then
 // one Newton correction with the residual evaluated in fp64.
+// (Round 3 tried a Laguerre step in front of four Newton steps -- 65 instead of 88 issue slots and, emulated against float64
+// roots on 655 360 rollout states, the same accuracy.  On the GPU it was 1.5 us per 2^20-env step SLOWER: the convergence test
+// below looks at the size of the LAST step, which after five iterations is still ~1e-4 t for lanes that have in fact arrived,
+// so most waves entered the safeguarded tail; it also failed the near-double-root family.  Not kept.)
 struct Quartic {
     float b2, b1, b0, ti;
 };
