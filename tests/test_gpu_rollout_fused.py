@@ -198,3 +198,34 @@ def test_ppo_one_launch_rollout_equals_the_three_launch_rollout(cfg, max_steps, 
     for k, (a, b) in enumerate(zip(*runs)):
         for i, (x, y) in enumerate(zip(a, b)):
             assert torch.equal(x, y), (k, i)
+
+
+@pytest.mark.parametrize("n,K,det", [(4, 1, False), (4, 7, True), (64, 3, True)])
+def test_fused_rollout_edge_sizes_and_deterministic_actions(cfg, n, K, det):
+    """One tile with mostly padding lanes, a single step, and `deterministic` (the mean action of model.predict(...,
+    deterministic=True), montecarlo_script.py): still the launch sequence bit for bit."""
+    import torch
+
+    (ea, eb), fused = _make(torch, n, cfg, (64, 64), False, 13, "rk4", clip_reward=(-1, 100), max_episode_steps=3)
+    for e in (ea, eb):
+        e.reset()
+    dev = ea.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    ref = {"obs_seq": torch.zeros((K + 1, n, 13), **f32), "raw_action": torch.zeros((K, n, 3), **f32), "value": torch.zeros((K, n), **f32),
+           "logp": torch.zeros((K, n), **f32), "reward": torch.zeros((K, n), **f32), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev),
+           "flags": torch.zeros((K, n), dtype=torch.uint8, device=dev)}
+    got = {k: torch.zeros_like(v) for k, v in ref.items()}
+    act = torch.zeros((n, 3), **f32)
+    ref["obs_seq"][0].copy_(ea.obs)
+    for j in range(K):
+        fused(ref["obs_seq"][j], deterministic=det, step_index=5 + j, out=(act, ref["raw_action"][j], ref["value"][j], ref["logp"][j]))
+        ea.step_into(act, obs=ref["obs_seq"][j + 1], reward=ref["reward"][j], done=ref["done"][j], flags=ref["flags"][j])
+    got["obs_seq"][0].copy_(eb.obs)
+    eb.rollout(fused, K, deterministic=det, policy_step_index=5, **got)
+    torch.cuda.synchronize()
+    for name in ref:
+        a, b = (ref[name][1:], got[name][1:]) if name == "obs_seq" else (ref[name], got[name])
+        assert torch.equal(a, b), name
+    assert torch.equal(ea.state, eb.state)
+    if det:   # the mean action carries no noise: its log-probability is that of the mode
+        assert float(ref["logp"].std()) == 0.0
