@@ -288,6 +288,10 @@ def small_batch_bound(n: int, integrator: str, dt, k: int, launch_s: float) -> d
     not by HBM.  VALU issue share of a launch = 4 x SQ_ACTIVE_INST_VALU (quad-cycles per launch, committed PMC pass of this
     workload, scripts/pmc_stepk.sh) / 1024 SIMDs / (2.4 GHz x this run's launch time); for a launch shape without a PMC pass
     only the bound's name is reported."""
+    if k <= 1:
+        return {"bound": "launch_latency", "launch_us": launch_s * 1e6,
+                "note": "one r6_step launch per env step: launch-to-launch time of a kernel whose tiles (one per wave) take one pass; the "
+                        "memory time of the step is ~1.5 us, its one-wave-per-SIMD compute ~5 us -- r6_step_k amortises the rest"}
     out = {"bound": "valu_issue_one_wave_per_simd", "unit": "share of the launch in which a SIMD issues a VALU instruction",
            "peak": 1.0, "launch_us": launch_s * 1e6}
     path = os.path.join(ROOT, STEPK_PROFILE)
