@@ -284,15 +284,15 @@ STEPK_PROFILE = os.path.join("profiles", "r3_pmc_stepk.json")
 
 
 def small_batch_bound(n: int, integrator: str, dt, k: int, launch_s: float) -> dict:
-    """BASELINE configs[1] (65 536 envs = 1024 tiles on 1024 SIMDs): the launch is bounded by what ONE wave per SIMD can issue,
-    not by HBM.  VALU issue share of a launch = 4 x SQ_ACTIVE_INST_VALU (quad-cycles per launch, committed PMC pass of this
+    """BASELINE configs[1] (65 536 envs = 1024 tiles on 1024 SIMDs): the launch is bounded by what one SIMD can issue for its one
+    tile (r6::step_k_pair_kernel: a dynamics wave and two reward waves per tile), not by HBM.  VALU issue share of a launch = 4 x SQ_ACTIVE_INST_VALU (quad-cycles per launch, committed PMC pass of this
     workload, scripts/pmc_stepk.sh) / 1024 SIMDs / (2.4 GHz x this run's launch time); for a launch shape without a PMC pass
     only the bound's name is reported."""
     if k <= 1:
         return {"bound": "launch_latency", "launch_us": launch_s * 1e6,
                 "note": "one r6_step launch per env step: launch-to-launch time of a kernel whose tiles (one per wave) take one pass; the "
                         "memory time of the step is ~1.5 us, its one-wave-per-SIMD compute ~5 us -- r6_step_k amortises the rest"}
-    out = {"bound": "valu_issue_one_wave_per_simd", "unit": "share of the launch in which a SIMD issues a VALU instruction",
+    out = {"bound": "valu_issue_of_one_simd_per_tile", "unit": "share of the launch in which a SIMD issues a VALU instruction",
            "peak": 1.0, "launch_us": launch_s * 1e6}
     path = os.path.join(ROOT, STEPK_PROFILE)
     if os.path.exists(path) and n == 65536 and integrator == "euler" and k == 16:
@@ -301,7 +301,8 @@ def small_batch_bound(n: int, integrator: str, dt, k: int, launch_s: float) -> d
             active = float(prof["raw_per_launch"]["SQ_ACTIVE_INST_VALU"])
             out["achieved"] = 4.0 * active / SIMDS / (ENGINE_CLOCK_HZ * launch_s)
             out["frac"] = out["achieved"]
-            out["valu_instructions_per_wave_and_env_step"] = prof["derived"]["valu_instructions_per_wave_and_env_step"]
+            out["valu_instructions_per_tile_and_env_step"] = prof["derived"]["valu_instructions_per_tile_and_env_step"]
+            out["kernel"] = prof.get("kernel")
             out["share_of_wave_cycles"] = prof["derived"]["share_of_wave_cycles"]
             out["source"] = f"{STEPK_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); engine clock taken at its 2.4 GHz peak"
         except Exception:

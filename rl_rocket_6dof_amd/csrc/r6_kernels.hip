@@ -1058,6 +1058,358 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
 }
 
 // -------------------------------------------------------------------------------------------------
+// r6_step_k for batches of at most one 64-env tile per SIMD (BASELINE configs[1]: 65 536 envs = 1024 tiles on 1024 SIMDs),
+// as TWO waves per tile.
+//
+// With one wave on a SIMD nothing hides that wave's own latencies: per-wave stamps of step_k_kernel (scripts/stepk_trace.py) put
+// a plain Euler step at 1.0 k cycles of dynamics + 2.2 k of reward + 1.3 k of outputs for ~610 VALU instructions -- a dependent
+// instruction every ~6.6 cycles, half of the issue slots empty -- and nothing in the state's evolution needs the reward.  So the
+// step is cut along that line and the halves run as three waves of one workgroup, placed on the same SIMD (waves w, w + 4, w + 8
+// of a 768-thread workgroup), connected by a ring of slots in LDS:
+//   wave A (w < 4):   action -> dynamics -> bounds / time limit -> done;  publishes the post-step state, the thrust vector, v0,
+//                     the flag bits and the step count;  done / flag stores, terminal observation, Rocket6DOF.reset of finished
+//                     envs (wave-wide Philox), observation -- everything the NEXT step needs, and nothing else;
+//   waves B_j (w + 4, w + 8): reward (the t_go quartic: the long dependent chain) of the steps with seq % 2 == j, fused reward
+//                     wrappers, reward / term stores; then, in step order (a counter in LDS), the running episode return,
+//                     episode records and statistics.  Two reward waves, because the reward is the longer half: one B wave took
+//                     2.0 us per step against A's 1.2 us of work.
+// (Per-wave stamps, scripts/stepk_pair_trace.py: B takes 2.0 us per step, A 1.2 us of work + waiting.  Moving the reward's cheap
+// half (limits, landing conditions, six of the seven terms) to A balanced the two waves at 1.9 / 2.0 us and changed nothing: the
+// pair is bound by what one SIMD issues for both; and products formed in one wave cannot contract with the sum formed in the
+// other, which costs the bit-exactness.  Not kept.)
+// A never waits for B's results, only for a free slot; B's loads are LDS reads.  Same device functions, same order of
+// operations per quantity as step_k_kernel: bit for bit the same outputs (tests/test_gpu_step_k.py runs both forms).
+// Every wait is bounded: a wave that does not see its partner's counter move for ~0.1 s raises the workgroup's abort word and
+// both leave (outputs then incomplete -- a partner that never arrives means the launch was broken anyway); the grid always drains.
+// -------------------------------------------------------------------------------------------------
+#ifndef R6_PAIR_RING
+#define R6_PAIR_RING 4
+#endif
+#ifndef R6_PAIR_NB
+#define R6_PAIR_NB 2   // reward waves per tile: wave B_j takes the steps with seq % NB == j (the reward is the longer half of a step)
+#endif
+constexpr int kPairTiles = 4, kPairNB = R6_PAIR_NB, kPairBlock = 64 * kPairTiles * (1 + kPairNB), kRing = R6_PAIR_RING, kSlotWords = 21;
+static_assert(kRing >= 2 * kPairNB, "the ring holds at least two steps per reward wave");
+
+// LDS words shared by the two waves of a pair.  The pointers carry the LDS address space explicitly: through a generic pointer
+// the poll becomes a flat load, which counts in vmcnt and would make every poll wait for the wave's outstanding global loads / stores.
+typedef __attribute__((address_space(3))) int* lds_word_t;
+__device__ __forceinline__ bool pair_wait(lds_word_t counter, int need, lds_word_t abort_word) {
+#pragma unroll 1
+    for (int spin = 0; spin < (1 << 21); ++spin) {
+        const int v = __builtin_amdgcn_readfirstlane(__atomic_load_n(counter, __ATOMIC_RELAXED));
+        if (v >= need) return true;
+        if (__builtin_amdgcn_readfirstlane(__atomic_load_n(abort_word, __ATOMIC_RELAXED)) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __atomic_store_n(abort_word, 1, __ATOMIC_RELAXED);
+    return false;
+}
+
+template <int INTEG, int SHAPING, int OD>
+__global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Params p, const R6Buffers b, const R6StepK sk, const uint64_t seed,
+                                                                    const uint64_t step_index, const uint64_t env_offset) {
+    static_assert(INTEG == R6_EULER || INTEG == R6_RK4, "fixed-step integrators (one sub-step per env step)");
+    __shared__ float ring[kPairTiles][kRing][kSlotWords][64];
+    __shared__ float ep_run[kPairTiles][64];                               // running episode return of a tile's envs, handed from reward wave to reward wave
+    __shared__ int produced[kPairTiles], consumed[kPairTiles][kPairNB], returned[kPairTiles], abort_word;
+    __shared__ float lds_inv_norm[R6_STATE_DIM];
+    __shared__ stat_t blk_stats[R6_NUM_STATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool role_b = wave >= kPairTiles;
+    const int slot_of = wave % kPairTiles;                      // the tile slot within the workgroup (waves t, t + 4, t + 8 share SIMD t)
+    const int par = role_b ? wave / kPairTiles - 1 : 0;         // reward wave j of the tile
+    const int64_t n = b.n, ld = b.ld;
+    const int64_t n_tiles = (n + 63) >> 6;
+    const int64_t nt = (int64_t)gridDim.x * kPairTiles;
+    const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
+    const int K = sk.k;
+    const bool last_only = (sk.flags & R6_K_LAST_ONLY) != 0;
+
+#ifdef R6_TRACE_K
+    const uint64_t pk0 = wall_clock64();
+    uint64_t pk1 = 0, pk2 = 0, pk_wait = 0;
+    int pk_ends = 0;
+#define PKWAIT(expr) ({ const uint64_t w0_ = __builtin_amdgcn_s_memtime(); const bool r_ = (expr); pk_wait += __builtin_amdgcn_s_memtime() - w0_; r_; })
+#else
+#define PKWAIT(expr) (expr)
+#endif
+    if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
+    if (tid < R6_STATE_DIM) lds_inv_norm[tid] = p.inv_norm[tid];
+    if (tid < kPairTiles) {
+        produced[tid] = 0;
+        returned[tid] = 0;
+#pragma unroll
+        for (int j = 0; j < kPairNB; ++j) consumed[tid][j] = 0;
+    }
+    if (tid == 0) abort_word = 0;
+    const uint64_t step_base = b.step_base ? *b.step_base : (uint64_t)0;
+    __syncthreads();
+
+    int seq = 0;   // steps this pair has gone through (its tiles one after the other): what the ring's counters count
+    bool ok = true;   // false: the partner never arrived (abort): leave the loops, still meet the workgroup at its last barrier
+#pragma unroll 1
+    for (int64_t t = (int64_t)blockIdx.x * kPairTiles + slot_of; ok && t < n_tiles; t += nt) {
+        const int64_t e0 = t * 64;
+        const int64_t rem = n - e0;
+        const bool live = lane < rem;
+        const int64_t i = e0 + lane;
+        const int lane_ld = live ? lane : 0;
+        if (!role_b) {
+            // ================================= wave A: what the next step needs ==========================================
+            float y[kDyn], mass = 4.0e4f, m0 = 4.0e4f, v0 = 0.0f;
+            uint32_t ep_step = 0u;
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) y[j] = (j == 0) ? 1000.0f : ((j == 6) ? 1.0f : 0.0f);   // benign padding lane
+            if (live) {
+                const float* row = b.state + e0;
+#pragma unroll
+                for (int j = 0; j < kDyn; ++j) {
+                    y[j] = uniform_ptr(row)[lane];
+                    row += ld;
+                }
+                mass = uniform_ptr(row)[lane];
+                m0 = uniform_ptr(b.epconst + e0)[lane];
+                v0 = uniform_ptr(b.epconst + (ld + e0))[lane];
+                if (has_ep) ep_step = uniform_ptr(b.ep_step + e0)[lane];
+            }
+            float a0, a1, a2;
+            {
+                const gptr<const float> act = uniform_ptr(b.action + e0 * R6_ACTION_DIM);
+                a0 = act[3 * lane_ld + 0];
+                a1 = act[3 * lane_ld + 1];
+                a2 = act[3 * lane_ld + 2];
+            }
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) asm volatile("" : "+v"(y[j]));
+            asm volatile("" : "+v"(mass), "+v"(m0), "+v"(v0), "+v"(ep_step));
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+#ifdef R6_TRACE_K
+            pk1 = wall_clock64();
+#endif
+#pragma unroll 1
+            for (int k = 0; k < K; ++k, ++seq) {
+                float n0, n1, n2;
+                {
+                    const int kn = (k + 1 < K) ? k + 1 : k;
+                    const gptr<const float> act = uniform_ptr(b.action + ((int64_t)kn * sk.action_stride + e0 * R6_ACTION_DIM));
+                    n0 = act[3 * lane_ld + 0];
+                    n1 = act[3 * lane_ld + 1];
+                    n2 = act[3 * lane_ld + 2];
+                }
+                const bool emit = !last_only || k + 1 == K;
+                const Control c = make_control_normalised(p, a0, a1, a2);
+                const Inertia J = make_inertia(m0);
+                const int status = integrate<INTEG, true, true>(y, mass, c, J, p.dt, 1);
+                const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
+                bool done = (status != 0) || bnd, truncated = false;
+                ep_step += 1u;
+                if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
+                    truncated = !done;
+                    done = true;
+                }
+                // ---- publish the step to wave B ----
+                {   // the slot about to be overwritten held step seq - kRing: its reward wave must have read it
+                    const int sp = seq - kRing;
+                    if (sp >= 0 && !PKWAIT(pair_wait((lds_word_t)&consumed[slot_of][sp % kPairNB], sp / kPairNB + 1, (lds_word_t)&abort_word))) {
+                        ok = false;
+                        break;
+                    }
+                }
+                {
+                    float(*sl)[64] = ring[slot_of][seq % kRing];
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) sl[j][lane] = y[j];
+                    sl[13][lane] = mass;
+                    sl[14][lane] = c.tbx;
+                    sl[15][lane] = c.tby;
+                    sl[16][lane] = c.tbz;
+                    sl[17][lane] = c.thrust;
+                    sl[18][lane] = v0;
+                    sl[19][lane] = __int_as_float((status == 1 ? 1 : 0) | (bnd ? 2 : 0) | (truncated ? 4 : 0) | (done ? 8 : 0));
+                    sl[20][lane] = __uint_as_float(ep_step);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __atomic_store_n((lds_word_t)&produced[slot_of], seq + 1, __ATOMIC_RELAXED);
+
+                // ---- observation, terminal observation, reset ----
+                float ob[OD];
+#pragma unroll
+                for (int j = 0; j < kDyn; ++j) {
+                    if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
+                }
+                if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
+                asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2) : : "memory");   // the prefetch has arrived: waited for in front of the stores
+                if (live && emit) {
+                    uniform_ptr(b.done + ((int64_t)k * sk.done_stride + e0))[lane] = done ? 1 : 0;
+                    if (b.flags)
+                        uniform_ptr(b.flags + ((int64_t)k * sk.flags_stride + e0))[lane] =
+                            (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
+                    if (b.nfev) uniform_ptr(b.nfev + ((int64_t)k * sk.nfev_stride + e0))[lane] = (uint8_t)(INTEG == R6_RK4 ? 4 : 1);
+                }
+                if (live && done && p.auto_reset && emit && b.final_obs) {
+                    float* fo = b.final_obs + ((int64_t)k * sk.final_obs_stride + i * OD);
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) fo[j] = ob[j];
+                }
+                if (p.auto_reset) {
+                    uint64_t fin = __ballot(live && done);
+                    if (fin != 0ull) {
+#ifdef R6_TRACE_K
+                        ++pk_ends;
+#endif
+                        const R6Params pp = load_params();
+                        do {
+                            const int j = __builtin_ctzll(fin);
+                            fin &= fin - 1ull;
+                            float ic[R6_STATE_DIM];
+                            sample_ic_wave(pp, seed, env_offset + (uint64_t)(e0 + j), step_index + (uint64_t)k + step_base, lane, ic);
+                            if (lane == j) {
+#pragma unroll
+                                for (int q = 0; q < kDyn; ++q) y[q] = ic[q];
+                                mass = m0 = ic[13];
+                                v0 = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
+                                ep_step = 0u;
+#pragma unroll
+                                for (int q = 0; q < OD; ++q) ob[q] = ic[q] * lds_inv_norm[q];
+                            }
+                        } while (fin != 0ull);
+                    }
+                }
+                if (emit && live) {
+                    float* dst = b.obs + ((int64_t)k * sk.obs_stride + i * OD);
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) dst[j] = ob[j];
+                }
+                a0 = n0;
+                a1 = n1;
+                a2 = n2;
+            }
+#ifdef R6_TRACE_K
+            pk2 = wall_clock64();
+#endif
+            if (live) {
+                float* row = b.state + e0;
+#pragma unroll
+                for (int j = 0; j < kDyn; ++j) {
+                    uniform_ptr(row)[lane] = y[j];
+                    row += ld;
+                }
+                uniform_ptr(row)[lane] = mass;
+                uniform_ptr(b.epconst + e0)[lane] = m0;
+                uniform_ptr(b.epconst + (ld + e0))[lane] = v0;
+                if (has_ep) uniform_ptr(b.ep_step + e0)[lane] = ep_step;
+            }
+        } else {
+            // ================================= wave B: reward, records =====================================================
+#ifdef R6_TRACE_K
+            pk1 = wall_clock64();
+#endif
+#pragma unroll 1
+            for (int k = 0; k < K; ++k, ++seq) {
+                if (seq % kPairNB != par) continue;   // another reward wave's step
+                const bool emit = !last_only || k + 1 == K;
+                if (!PKWAIT(pair_wait((lds_word_t)&produced[slot_of], seq + 1, (lds_word_t)&abort_word))) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float y[kDyn], mass, v0;
+                Control c;
+                int fl;
+                uint32_t ep_step;
+                {
+                    const float(*sl)[64] = ring[slot_of][seq % kRing];
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) y[j] = sl[j][lane];
+                    mass = sl[13][lane];
+                    c.tbx = sl[14][lane];
+                    c.tby = sl[15][lane];
+                    c.tbz = sl[16][lane];
+                    c.thrust = sl[17][lane];
+                    c.mdot = 0.0f;   // not used by the reward
+                    v0 = sl[18][lane];
+                    fl = __float_as_int(sl[19][lane]);
+                    ep_step = __float_as_uint(sl[20][lane]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads above are done (LDS operations of a wave complete in order)
+                if (lane == 0) __atomic_store_n((lds_word_t)&consumed[slot_of][par], seq / kPairNB + 1, __ATOMIC_RELAXED);
+                const bool ground = (fl & 1) != 0, bnd = (fl & 2) != 0, truncated = (fl & 4) != 0, done = (fl & 8) != 0;
+
+                const R6Params pr = load_params();
+                RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
+                const bool landed = rw.landed;
+                float rew = finalize_reward(pr, rw, bnd, fmaf(2.0f * c.thrust, frcp(pr.max_thrust), -1.0f), y);
+                if (live && emit && b.terms) {
+                    float* trow = b.terms + ((int64_t)k * sk.terms_stride + i);
+#pragma unroll
+                    for (int q = 0; q < R6_NUM_TERMS; ++q) {
+                        *trow = rw.terms[q];
+                        trow += ld;
+                    }
+                }
+                if (pr.clip_reward) rew = fminf(fmaxf(rew, pr.clip_lo), pr.clip_hi);
+                if (live && emit) uniform_ptr(b.reward + ((int64_t)k * sk.reward_stride + e0))[lane] = rew;
+                // ---- the running episode return: a chain through the steps, handed from reward wave to reward wave in LDS ----
+                if (!PKWAIT(pair_wait((lds_word_t)&returned[slot_of], seq, (lds_word_t)&abort_word))) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float ep_ret = 0.0f;
+                if (k == 0) {
+                    if (live && has_ep) ep_ret = uniform_ptr(b.ep_return + e0)[lane];
+                } else {
+                    ep_ret = ep_run[slot_of][lane];
+                }
+                ep_ret += rew;
+                if (live && done) {
+                    if (b.stats) stats_add_episode(blk_stats, ep_ret, ep_step, ground, bnd, truncated, landed);
+                    if (p.auto_reset) {
+                        if (emit) {
+                            if (b.fin_return) b.fin_return[(int64_t)k * sk.fin_stride + i] = ep_ret;
+                            if (b.fin_length) b.fin_length[(int64_t)k * sk.fin_stride + i] = ep_step;
+                        }
+                        ep_ret = 0.0f;
+                    }
+                }
+                if (k + 1 == K) {
+                    if (live && has_ep) uniform_ptr(b.ep_return + e0)[lane] = ep_ret;
+                } else {
+                    ep_run[slot_of][lane] = ep_ret;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __atomic_store_n((lds_word_t)&returned[slot_of], seq + 1, __ATOMIC_RELAXED);
+            }
+#ifdef R6_TRACE_K
+            pk2 = wall_clock64();
+#endif
+        }
+    }
+#ifdef R6_TRACE_K
+    __builtin_amdgcn_s_waitcnt(0);
+    if (b.stats && lane == 0) {
+        double* o = b.stats + ((int64_t)blockIdx.x * (kPairBlock / 64) + wave) * R6_NUM_STATS;
+        o[0] = (double)(uint32_t)pk0;
+        o[1] = (double)(uint32_t)pk1;
+        o[2] = (double)(uint32_t)pk2;
+        o[3] = (double)(uint32_t)wall_clock64();
+        o[4] = (double)pk_ends;
+        o[5] = (double)pk_wait;
+        o[6] = role_b ? 1.0 : 0.0;
+    }
+    return;
+#endif
+
+    __syncthreads();
+    if (b.stats && tid < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] != 0ull)
+        b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
+}
+
+// -------------------------------------------------------------------------------------------------
 // Rocket6DOF.reset (env:180-199) for masked envs.
 // -------------------------------------------------------------------------------------------------
 template <int OD>
@@ -1404,6 +1756,20 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
 
 template <int INTEG, int SHAPING, int OD>
 void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
+    if constexpr (INTEG != R6_RK45) {
+        // at most one 64-env tile per SIMD: the two-waves-per-tile form (step_k_pair_kernel).  R6_K_PAIR=0|1 overrides.
+        static const int pair_env = [] { const char* e = std::getenv("R6_K_PAIR"); return e ? std::atoi(e) : -1; }();
+        const int64_t n_tiles = (b.n + 63) / 64;
+        const bool pair = p.n_substeps == 1 && (pair_env >= 0 ? pair_env != 0 : n_tiles <= R6_K_DIRECT_MAX_TILES);
+        if (pair) {
+            int64_t blocks = (n_tiles + r6::kPairTiles - 1) / r6::kPairTiles;
+            if (blocks > R6_MAX_BLOCKS) blocks = R6_MAX_BLOCKS;
+            R6StepK skl = sk;
+            skl.flags = sk.flags & ~R6_K_DIRECT_OBS_INTERNAL;
+            hipLaunchKernelGGL((r6::step_k_pair_kernel<INTEG, SHAPING, OD>), dim3((unsigned)blocks), dim3(r6::kPairBlock), 0, s, p, b, skl, seed, step, off);
+            return;
+        }
+    }
     auto kernel = r6::step_k_kernel<INTEG, SHAPING, OD, false>;
     if constexpr (INTEG != R6_RK45) {
         if (p.n_substeps == 1) kernel = r6::step_k_kernel<INTEG, SHAPING, OD, true>;

@@ -20,14 +20,14 @@ import csv, glob, collections, json
 res = collections.OrderedDict()
 dur = []
 for f in sorted(glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True)):
-    rows = [r for r in csv.DictReader(open(f)) if "step_k_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if "step_k_" in r["Kernel_Name"]]
     by = collections.defaultdict(list)
     for r in rows: by[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in by.items():
         v = v[-30:]
         res[k] = sum(v) / len(v)
 for f in sorted(glob.glob("$OUT/g1/**/*kernel_trace.csv", recursive=True)):
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if "step_k_kernel" in r["Kernel_Name"]][-30:]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if "step_k_" in r["Kernel_Name"]][-30:]
     if d: res["launch_us_under_counters"] = sum(d) / len(d)
 res["driver_line"] = open("$OUT/g1.log").read().strip().split("\n")[-1]
 json.dump(res, open("$OUT/summary.json", "w"), indent=1)
