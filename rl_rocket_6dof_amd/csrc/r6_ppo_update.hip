@@ -9,10 +9,10 @@
 // weight-gradient products (64 x 65536)(65536 x 128) are the expensive ones -- and ~40 elementwise / reduction kernels:
 // 0.52 ms of GPU time for 65 536 samples.  Here a wave owns a tile of 32 samples (the MFMA column block):
 //
-//   forward   z1 = W1 x, a1 = tanh z1, z2 = W2 a1, a2 = tanh z2 on the matrix cores (v_mfma_f32_32x32x2_f32: exact
-//             fp32 products and accumulation, so the gradients carry no reduced-precision term), out^T[feature][sample]
-//             = W[feature][k] * act^T[k][sample] as in r6_policy.hip: a layer's accumulator block IS the next layer's
-//             B operand; heads (4 outputs) on the VALU;
+//   forward   z1 = W1 x, a1 = tanh z1, z2 = W2 a1, a2 = tanh z2 on the matrix cores, out^T[feature][sample] = W[feature][k] *
+//             act^T[k][sample] as in r6_policy.hip: a layer's accumulator block IS the next layer's B operand; f16 hi + lo splits
+//             of both operands with fp32 accumulation by default, v_mfma_f32_32x32x2_f32 (exact fp32 products) with
+//             R6U_F16_FWD=0 -- the accuracy of both against float64 autograd is recorded below; heads (4 outputs) on the VALU;
 //   loss      per sample, the formulas of r6_ppo_loss_grad -> g = d loss / d (mean0, mean1, mean2, value);
 //   backward  delta2 = (W3^T g) (1 - a2^2) on the VALU; delta1 = (W2^T delta2) (1 - a1^2) on the matrix cores through
 //             a W2^T image, delta2's accumulator-layout registers being the B operand again;
@@ -54,28 +54,47 @@ constexpr int kOffFeat = kNumBlocks * 1024, kOffScal = kOffFeat + kFeat;
 constexpr int kPartial = kOffScal + kScalars;   // one workgroup's partial set: [blocks][feat][scalars]
 #ifdef R6U_STAMPS
 constexpr int kStampSlots = 20;
+#ifndef R6U_STAMP_SET
+#define R6U_STAMP_SET 0   // 1: the staging in four parts, 2: the end-of-launch reduction in four parts (scripts/ppo_grad_fixed_cost.py --set=N)
+#endif
 #endif
 constexpr float kExpScale = 2.8853900817779268f;   // 2 / ln 2
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-// The layer products whose B operand is an activation block in accumulator layout -- forward layers 1 and 2 (160 full-size MFMAs of a
-// tile), the delta1 chains (128) -- can run as v_mfma_f32_32x32x16_f16 on f16 hi + lo splits of both operands (three or four products
-// per K-step of 16, fp32 accumulation; the scheme of r6_policy.hip) instead of v_mfma_f32_32x32x2_f32.  Measured on MI355X
-// (scripts/ppo_grad_ab.py, 65 536 samples, gradient + reduce): exact fp32 everywhere 63.4 us; delta1 chains in f16 (R6U_F16_BWD, the
-// default): see DESIGN.md section 7; forward AND delta1 in f16: 52.2-53.1 us -- but a two-term f16 split keeps 22 of an operand's 24
-// bits, and the forward's error reaches every gradient through the loss: the value head's bias gradient, a sum over the samples that
-// cancels to a few per cent of its terms, then misses the autograd test's 2e-5 by 1.4x (9.7e-8 against 7.0e-8 absolute, 300
-// samples, two (64, 64) MLPs; all other 17 parametrisations pass).  So the forward stays exact by default (R6U_F16_FWD=1 is the
-// measured-and-not-shipped variant); the delta operands, scaled per tile by a power of two, only feed dW1 / db1, which tolerate it.
-// The weight-gradient products (contraction over the samples) stay exact fp32 in every mode.
+// Every layer product of the kernel except dW1 can run as v_mfma_f32_32x32x16_f16 on f16 hi + lo splits of both operands (three or
+// four products per K-step of 16, fp32 accumulation; the scheme of r6_policy.hip) instead of v_mfma_f32_32x32x2_f32 -- 1/16 of the
+// matrix time per K for 3-4x the instructions:
+//   R6U_F16_FWD   forward layers 1 and 2 (B operand = an activation block in accumulator layout), all four partial products;
+//   R6U_F16_BWD   the delta1 chains; delta2 is scaled per tile by a power of two first (gradients carry 1 / n and have any magnitude);
+//   R6U_F16_DW2   dW2 = delta2 a1^T (contraction over the samples), the scaled delta2 again: a tile's products are summed in a block
+//                 of their own and join the launch's sums times the inverse factor.
+// The split keeps hi = the operand rounded towards zero to f16 and lo = the remainder ROUNDED TO NEAREST (R6U_SPLIT_LO_RN): 22-23 of
+// the 24 bits, unbiased.  With a truncated lo (round 2's split, one v_cvt_pkrtz for both halves) every product errs the same way and
+// sums over the samples keep the bias: the value head's bias gradient, which cancels to a few per cent of its terms, then missed
+// the autograd test's 2e-5 by 1.4x; with the rounded lo the f16 forms are as close to FLOAT64 autograd as the exact-fp32 kernel and as
+// torch's own fp32 autograd (scripts/ppo_grad_accuracy.py: worst gradient entry 0.5-3.6e-6 of its tensor's largest, torch fp32
+// 0.5e-6-1.5e-5, exact-fp32 kernel 0.5-6.7e-6).  Measured on MI355X (scripts/ppo_grad_ab.py, 65 536 samples, gradient + reduce
+// launches): exact fp32 everywhere 63.4 us; delta1 chains in f16 58.2; + this round's staging / end-of-launch reduction 50.6;
+// + f16 forward 45.9; + f16 dW2 42.6 us (two (64, 64) MLPs: 67.4 -> 50.3).  dW1 (16x16x4 fp32, 2048 cycles of a tile) stays exact:
+// delta1 has no cheap bound for an f16 scale.  All three default to 1; =0 gives the exact-fp32 forms back.
 #ifndef R6U_F16_FWD
-#define R6U_F16_FWD 0
+#define R6U_F16_FWD 1
 #endif
 #ifndef R6U_F16_BWD
 #define R6U_F16_BWD 1
 #endif
 #define R6U_F16_ANY (R6U_F16_FWD || R6U_F16_BWD)
+#ifndef R6U_SPLIT_LO_RN
+#define R6U_SPLIT_LO_RN 1
+#endif
+#ifndef R6U_F16_DW2
+#define R6U_F16_DW2 R6U_F16_BWD
+#endif
+#if R6U_F16_DW2 && !R6U_F16_BWD
+#error "R6U_F16_DW2 uses the delta-chain scaling of R6U_F16_BWD"
+#endif
+#define R6U_FAST_STAGING R6U_F16_BWD   // images with f16 delta-chain fragments (either forward form): staged with every load in flight at once
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 struct Split {
@@ -83,7 +102,12 @@ struct Split {
 };
 __device__ __forceinline__ void split2(float a, float b, h2& hi, h2& lo) {
     hi = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+#if R6U_SPLIT_LO_RN
+    lo[0] = (_Float16)(a - (float)hi[0]);   // round to nearest: a truncated lo term biases every product the same way, and sums over the samples keep the bias
+    lo[1] = (_Float16)(b - (float)hi[1]);
+#else
     lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+#endif
 }
 __device__ __forceinline__ Split split8(const float (&x)[8]) {
     Split s;
@@ -114,6 +138,9 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
 }
 
+#ifndef R6U_FWD_MFMA
+#define R6U_FWD_MFMA mfma4
+#endif
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 // 16 x 16 output, K = 4 per instruction (lane l: A row / B column l % 16, k = l / 16; D register r: row 4 (l / 16) + r, column l % 16):
@@ -239,7 +266,196 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #ifdef R6U_STAMPS
     const uint64_t ts0 = wall_clock64();
 #endif
+    // ---- the first tiles' rows are asked for before anything else: their round trips run under the staging's ---------------
+    const int64_t n_tiles = (a.n + 31) >> 5;
+    // The gathers of a tile (its 32 rows of obs / action / old_logp / adv / ret, found through the index) are two dependent
+    // memory round trips, and nobody hides them at one wave per SIMD: 1 us of a 21 us tile while the rollout buffer sits in
+    // L2, several when it is 2^24 rows in HBM.  So they run one tile ahead: the next tile's row number is requested at the
+    // top of a tile, its data after the loss (those registers are free during the backward pass), and both are consumed
+    // in the next trip.  Row -1 = no sample (padding lane or no further tile).
+    const int64_t t_stride = (int64_t)gridDim.x * kWaves;
+    auto fetch_row = [&](int64_t tt) __attribute__((always_inline)) -> int {
+        const int64_t sidx = tt * 32 + col;
+        return (tt < n_tiles && sidx < a.n) ? (int)(a.index ? a.index[sidx] : sidx) : -1;
+    };
+    auto fetch_data = [&](int r, float (&x)[8], float (&sv)[6]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = R6U_F16_FWD ? s + 8 * h : 2 * s + h;   // the K layout of the layer-1 MFMA: 8 consecutive features per lane half (f16, K = 16) or interleaved (f32, K = 2 per step)
+            x[s] = 0.0f;
+            if (r >= 0) {
+                if (k < OD) x[s] = a.obs[(int64_t)r * OD + k];
+                else if (k == OD) x[s] = 1.0f;   // the bias column
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sv[q] = 0.0f;
+        if (r >= 0) {
+            sv[0] = a.action[3 * (int64_t)r + 0];
+            sv[1] = a.action[3 * (int64_t)r + 1];
+            sv[2] = a.action[3 * (int64_t)r + 2];
+            sv[3] = a.old_logp[r];
+            sv[4] = a.adv[r];
+            sv[5] = a.ret[r];
+        }
+    };
+    const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
+    int row_cur = fetch_row(t_first), row_next = fetch_row(t_first + t_stride);
+    float xk[8], sv[6];   // x: this lane's 8 features k = 2s + h of its sample (B operand of layer 1); sv: action[3], old_logp, adv, ret
     // ---- stage the weight images -------------------------------------------------------------------------------------
+#if R6U_FAST_STAGING
+    // Every workgroup builds the same images from the same ~40 KB of parameters, and at one wave per SIMD nobody hides a round
+    // trip to L2 (about 1 us with 256 workgroups asking at once): so ALL of a thread's loads are issued first -- W2 as eight
+    // 16-byte loads per thread, each of them four consecutive k of one row = one ds_write_b128 of the layer-2 image and four
+    // lanes' halves of a delta-chain fragment -- and the LDS writes follow in one go.  (As four dependent loops this took
+    // 7.2 us of a 55 us launch: scripts/ppo_grad_fixed_cost.py.)
+    constexpr int kW2V = NETS * H2 * H1 / (4 * kBlock), kW1N = NETS * B1 * 64 * 8 / kBlock, kW3N = (Im::kW3 + kBlock - 1) / kBlock;
+    static_assert(NETS * H2 * H1 % (4 * kBlock) == 0 && NETS * B1 * 64 * 8 % kBlock == 0 && Im::kB2 <= kBlock && H1 % 4 == 0, "whole rounds");
+    constexpr int kFragN = NETS * B1 * B2 * 2 / kWaves;   // delta-chain fragments (chain, K-step) per wave
+    static_assert(NETS * B1 * B2 * 2 % kWaves == 0, "whole rounds");
+#if defined(R6U_STAMPS) && R6U_STAMP_SET == 1
+    uint64_t tsa = 0, tsb = 0, tsc = 0;
+#endif
+    auto put_frag = [&](int frag_float_off, const float (&v)[8]) __attribute__((always_inline)) {   // a lane's 8 halves of a fragment: hi copy, then lo copy
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (_Float16)v[j];
+            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        }
+        h8* dst = reinterpret_cast<h8*>(lds) + frag_float_off / 4 + lane;
+        dst[0] = hi;
+        dst[Im::kFrag / 4] = lo;
+    };
+    float w2tv[kFragN][8];
+    float w3v[kW3N], b2v = 0.0f;
+#if R6U_F16_FWD
+    // f16 forward: layer 2's fragments like the delta chain's, lane = (row m of W2, lane half), the 8 halves of a K-step = two runs
+    // of four consecutive k of that row; layer 1 has one fragment per chain (K = 16 covers the observation and the bias column)
+    static_assert(NETS * B1 == kWaves, "one layer-1 fragment per wave");
+    float w2fv[kFragN][8], w1fv[8];
+#else
+    f32x4 w2v[kW2V];
+    float w1v[kW1N];
+#endif
+    {
+#if R6U_F16_FWD
+#pragma unroll
+        for (int i = 0; i < kFragN; ++i) {
+            const int fi = wave + kWaves * i, chain = fi >> 1, st = fi & 1;   // chain (net * B2 + mb) * B1 + b
+            const int b = chain % B1, mb = (chain / B1) % B2, ni = chain / (B2 * B1);
+            const float* w = (ni ? net.vf_w2 : net.pi_w2) + (mb * 32 + col) * H1 + 32 * b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w2fv[i][j] = w[rowmap(8 * st + j, h)];
+        }
+        {
+            const int ni = wave / B1, blk = wave % B1, m = blk * 32 + col;
+            const float* w = (ni ? net.vf_w1 : net.pi_w1) + m * OD;
+            const float* bb = (ni ? net.vf_b1 : net.pi_b1) + m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * h + j;
+                const float v = *((k < OD) ? w + k : bb);
+                w1fv[j] = (k <= OD) ? v : 0.0f;
+            }
+        }
+#else
+        const bool vec = ((reinterpret_cast<uintptr_t>(net.pi_w2) | (NETS == 2 ? reinterpret_cast<uintptr_t>(net.vf_w2) : 0)) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < kW2V; ++i) {
+            const int f = tid + kBlock * i, ni = f / (H2 * H1 / 4), loc = f % (H2 * H1 / 4);
+            const float* w = (ni ? net.vf_w2 : net.pi_w2) + 4 * loc;
+            if (vec) {
+                w2v[i] = *reinterpret_cast<const f32x4*>(w);
+            } else {   // parameters that are views at odd offsets of one flat buffer
+                w2v[i][0] = w[0];
+                w2v[i][1] = w[1];
+                w2v[i][2] = w[2];
+                w2v[i][3] = w[3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kW1N; ++i) {
+            const int e = tid + kBlock * i;
+            const int sidx = e & 7, l = (e >> 3) & 63, chain = e >> 9;   // chain = net * B1 + blk
+            const int ni = chain / B1, blk = chain % B1;
+            const int k = 2 * sidx + (l >> 5), m = blk * 32 + (l & 31);
+            const float* w = ni ? net.vf_w1 : net.pi_w1;
+            const float* b = ni ? net.vf_b1 : net.pi_b1;
+            const float v = *((k < OD) ? w + m * OD + k : b + m);   // one unconditional load (a load under a lane mask makes the compiler wait for everything in flight)
+            w1v[i] = (k <= OD) ? v : 0.0f;
+        }
+#endif
+        // W2 once more, as the delta chain wants it: a wave builds whole fragments, lane = (column n of W2, lane half), its 8 halves
+        // = 8 rows of that column -- eight loads that are contiguous across the lanes, and one 16-byte LDS write each for the hi
+        // and the lo copy.  (Scattering the row-major float4s above into the fragments as 2-byte writes ran into 8- to 16-way
+        // bank conflicts: 64 ds_write_b16 per thread cost more than the loads.)
+#pragma unroll
+        for (int i = 0; i < kFragN; ++i) {
+            const int fi = wave + kWaves * i, chain = fi >> 1, st = fi & 1;   // chain (net * B1 + ib) * B2 + c
+            const int c = chain % B2, ib = (chain / B2) % B1, ni = chain / (B2 * B1);
+            const float* w = (ni ? net.vf_w2 : net.pi_w2) + ib * 32 + col;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w2tv[i][j] = w[(32 * c + rowmap(8 * st + j, h)) * H1];
+        }
+        if (tid < Im::kB2) {   // ((net * B2 + mb) * 2 + h) * 16 + r
+            const int r = tid & 15, hh = (tid >> 4) & 1, rest = tid >> 5;
+            const int ni = rest / B2, mb = rest % B2;
+            b2v = (ni ? net.vf_b2 : net.pi_b2)[mb * 32 + rowmap(r, hh)];
+        }
+#pragma unroll
+        for (int i = 0; i < kW3N; ++i) {   // (((net * 2 + h) * B2 + mb) * 16 + r) * 4 + o
+            const int e = tid + kBlock * i;
+            const int o = e & 3, r = (e >> 2) & 15, rest = e >> 6;
+            const int c = rest % B2, hh = (rest / B2) & 1, ni = rest / (2 * B2);
+            const int k = 32 * c + rowmap(r, hh);
+            static_assert(Im::kW3 % kBlock == 0, "whole rounds");
+            const bool act_head = o < 3;
+            const float v = *(act_head ? net.pi_w3 + o * H2 + k : net.vf_w3 + k);
+            w3v[i] = (NETS == 1 || (ni == 0) == act_head) ? v : 0.0f;   // two MLPs: net 0 feeds the action head only, net 1 the value head only
+        }
+#if defined(R6U_STAMPS) && R6U_STAMP_SET == 1
+        __builtin_amdgcn_sched_barrier(0);
+        tsa = wall_clock64();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        fetch_data(row_cur, xk, sv);   // the first tile's samples: requested behind the parameters, consumed after the barrier
+#if defined(R6U_STAMPS) && R6U_STAMP_SET == 1
+        __builtin_amdgcn_sched_barrier(0);
+        tsb = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tsc = wall_clock64();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (tid < Im::kB2) lds[Im::oB2 + tid] = b2v;
+#pragma unroll
+        for (int i = 0; i < kW3N; ++i) {
+            lds[Im::oW3 + tid + kBlock * i] = w3v[i];
+        }
+#if R6U_F16_FWD
+        put_frag(Im::oW1 + wave * 2 * Im::kFrag, w1fv);
+#pragma unroll
+        for (int i = 0; i < kFragN; ++i) put_frag(Im::oW2 + (wave + kWaves * i) * 2 * Im::kFrag, w2fv[i]);
+#else
+#pragma unroll
+        for (int i = 0; i < kW1N; ++i) {
+            const int e = tid + kBlock * i;
+            lds[Im::oW1 + (e >> 3) * kP1 + (e & 7)] = w1v[i];   // (chain * 64 + l) * kP1 + s
+        }
+#pragma unroll
+        for (int i = 0; i < kW2V; ++i) {
+            const int f = tid + kBlock * i, ni = f / (H2 * H1 / 4), loc = f % (H2 * H1 / 4);
+            const int m = loc / (H1 / 4), k0 = 4 * (loc % (H1 / 4));          // W2[m][k0 .. k0 + 3]
+            // layer-2 image, chain (net * B2 + mb) * B1 + b: lane (m % 32) + 32 h, registers r0 .. r0 + 3 with rowmap(r0 + i, h) = k0 % 32 + i
+            const int chain = (ni * B2 + (m >> 5)) * B1 + (k0 >> 5);
+            const int l = (m & 31) + 32 * ((k0 >> 2) & 1), r0 = 4 * ((k0 >> 3) & 3);
+            *reinterpret_cast<f32x4*>(lds + Im::oW2 + (chain * 64 + l) * kP2 + r0) = w2v[i];
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < kFragN; ++i) put_frag(Im::oW2T + (wave + kWaves * i) * 2 * Im::kFrag, w2tv[i]);   // fragment (chain * 2 + step)
+    }
+#else
 #if R6U_F16_ANY
     _Float16* ldsh = reinterpret_cast<_Float16*>(lds);
     auto put_split = [&](int frag_float_off, int e, float v) __attribute__((always_inline)) {   // e = lane * 8 + elem within the fragment
@@ -309,6 +525,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         else v = (o == 3) ? net.vf_w3[k] : 0.0f;
         lds[Im::oW3 + e] = v;
     }
+#endif
     __syncthreads();
 
 #ifdef R6U_STAMPS
@@ -382,42 +599,9 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         for (int r = 0; r < 4; ++r) acc1[k][0][r] = acc1[k][1][r] = 0.0f;
     }
 
-    const int64_t n_tiles = (a.n + 31) >> 5;
-    // The gathers of a tile (its 32 rows of obs / action / old_logp / adv / ret, found through the index) are two dependent
-    // memory round trips, and nobody hides them at one wave per SIMD: 1 us of a 21 us tile while the rollout buffer sits in
-    // L2, several when it is 2^24 rows in HBM.  So they run one tile ahead: the next tile's row number is requested at the
-    // top of a tile, its data after the loss (those registers are free during the backward pass), and both are consumed
-    // in the next trip.  Row -1 = no sample (padding lane or no further tile).
-    const int64_t t_stride = (int64_t)gridDim.x * kWaves;
-    auto fetch_row = [&](int64_t tt) __attribute__((always_inline)) -> int {
-        const int64_t sidx = tt * 32 + col;
-        return (tt < n_tiles && sidx < a.n) ? (int)(a.index ? a.index[sidx] : sidx) : -1;
-    };
-    auto fetch_data = [&](int r, float (&x)[8], float (&sv)[6]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = R6U_F16_FWD ? s + 8 * h : 2 * s + h;   // the K layout of the layer-1 MFMA: 8 consecutive features per lane half (f16, K = 16) or interleaved (f32, K = 2 per step)
-            x[s] = 0.0f;
-            if (r >= 0) {
-                if (k < OD) x[s] = a.obs[(int64_t)r * OD + k];
-                else if (k == OD) x[s] = 1.0f;   // the bias column
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) sv[q] = 0.0f;
-        if (r >= 0) {
-            sv[0] = a.action[3 * (int64_t)r + 0];
-            sv[1] = a.action[3 * (int64_t)r + 1];
-            sv[2] = a.action[3 * (int64_t)r + 2];
-            sv[3] = a.old_logp[r];
-            sv[4] = a.adv[r];
-            sv[5] = a.ret[r];
-        }
-    };
-    const int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
-    int row_cur = fetch_row(t_first), row_next = fetch_row(t_first + t_stride);
-    float xk[8], sv[6];   // x: this lane's 8 features k = 2s + h of its sample (B operand of layer 1); sv: action[3], old_logp, adv, ret
+#if !R6U_FAST_STAGING
     fetch_data(row_cur, xk, sv);
+#endif
 #pragma unroll 1
     for (int64_t t = t_first; t < n_tiles; t += t_stride) {
         const bool live = row_cur >= 0;
@@ -462,7 +646,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.0f;
                 const int f = (Im::oW1 + (ni * B1 + blk) * 2 * Im::kFrag) / 4 + lane;
-                z = mfma4(frag[f], frag[f + Im::kFrag / 4], xs, z);
+                z = R6U_FWD_MFMA(frag[f], frag[f + Im::kFrag / 4], xs, z);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[ni][blk][r] = tanh_fast(z[r]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -486,7 +670,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
                     for (int mb = 0; mb < B2; ++mb) {
                         const int f = (Im::oW2 + ((((ni * B2 + mb) * B1 + b) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
-                        z2[mb] = mfma4(frag[f], frag[f + Im::kFrag / 4], bs, z2[mb]);
+                        z2[mb] = R6U_FWD_MFMA(frag[f], frag[f + Im::kFrag / 4], bs, z2[mb]);
                     }
                     asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
                 }
@@ -657,7 +841,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             // tile is scaled by a power of two first -- exact -- such that its largest entry sits in [2^13, 2^14): far from f16's
             // 65504, and every entry down to 2^-16 of the largest one still splits into a normal hi and a normal-or-exact lo
             Split d2s[B2][2];
-            float d2_unscale;
+            float d2_unscale, d2_scale;
             {
                 float m = 0.0f;
 #pragma unroll
@@ -670,6 +854,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;     // floor(log2 m); -127 for zero / denormal
                 if (e < -100) e = -100;                                      // nothing to scale: keep the factor finite
                 const float scale = __uint_as_float((uint32_t)(127 + 13 - e) << 23);
+                d2_scale = scale;
                 d2_unscale = __uint_as_float((uint32_t)(127 - 13 + e) << 23);
 #pragma unroll
                 for (int c = 0; c < B2; ++c) {
@@ -687,6 +872,22 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             ldv<16>(tr_base + Im::sT2, dT[0]);
             ldv<16>(tr_base + Im::sT2 + 32 * kPitch, dT[1]);
             ldv<8>(tr4_base + Im::sX, bxc);   // x's row l % 16, samples g, g + 4, ...: B of the 16x16x4 product below
+#if R6U_F16_DW2
+            // dW2 on the f16 matrix pipe as well: a lane half's 16 samples of a row are two K-steps of 8 -- the operands the fp32
+            // chains step through two at a time, split as they are.  delta2 goes in scaled like above, so a tile's products are
+            // summed in a block of their own and join the launch's sums times the inverse factor (exact powers of two).
+            Split dTs[B2][2];
+#pragma unroll
+            for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = dT[mb][8 * sk + j] * d2_scale;
+                    dTs[mb][sk] = split8(v);
+                }
+            }
+#endif
 #pragma unroll
             for (int ib = 0; ib < B1; ++ib) {
                 wave_sync();   // the block buffer's previous readers are done
@@ -704,12 +905,33 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #if !R6U_F16_BWD
                     ldv<16>(&lds[Im::oW2T + (((ni * B1 + ib) * B2 + 0) * 64 + lane) * kP2], op[0]);
 #endif
+#if R6U_F16_DW2
+                    Split bas[2];
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = ba[8 * sk + j];
+                        bas[sk] = split8(v);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) {
+                        f32x16 part;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+#pragma unroll
+                        for (int sk = 0; sk < 2; ++sk) part = mfma3(dTs[mb][sk].hi, dTs[mb][sk].lo, bas[sk], part);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[iW2(ni, mb, ib)][r] = fmaf(part[r], d2_unscale, acc[iW2(ni, mb, ib)][r]);
+                    }
+#else
 #pragma unroll
                     for (int s = 0; s < 16; ++s) acc[iW2(ni, 0, ib)] = mfma(dT[0][s], ba[s], acc[iW2(ni, 0, ib)]);
                     R6U_CHAIN_FENCE();
 #pragma unroll
                     for (int s = 0; s < 16; ++s) acc[iW2(ni, 1, ib)] = mfma(dT[1][s], ba[s], acc[iW2(ni, 1, ib)]);
                     R6U_CHAIN_FENCE();
+#endif
                 }
                 R6U_MARK(5 + 3 * ib);   // G2
                 // delta1[i][s] = (sum_f2 W2[f2][i] delta2[f2][s]) (1 - a1[i][s]^2)
@@ -770,80 +992,115 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     float sc[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) sc[k] = (R6U_F16_ANY && h != 0) ? 0.0f : lds[o_stat + k * kStatStride];   // (own area: the two halves of an env share a slot)
-    __syncthreads();
-    float* reds = lds;                             // [kWaves][kScalars]: the weight images are not needed any more
+    __syncthreads();                               // every wave has left the tile loop: images and staging areas are free
+#if defined(R6U_STAMPS) && R6U_STAMP_SET == 2
+    const uint64_t tsa = wall_clock64();
+#endif
+    // One exchange, one barrier.  Wave q finishes the quarter q of the accumulators: dW2 blocks 2q and 2q + 1 and dW1 block q,
+    // 40 registers.  Every wave parks the three quarters it does not own in LDS -- [source wave][quarter][10][lane] float4, read
+    // back by the same lane of the owner, so any layout is conflict-free -- next to its scalars and per-feature sums; after the
+    // barrier the owner adds the four contributions in the fixed order (w0 + w1) + (w2 + w3), its own from registers, and
+    // stores the blocks in canonical [m][n] order.  No atomics, and the sum does not depend on timing.  (Round 2 drained four
+    // blocks at a time through the staging areas, twelve barriers: 7 us of a 55 us launch -- scripts/ppo_grad_fixed_cost.py.)
+    constexpr int kXchWave = 3 * 10 * 64 * 4, kXch = kWaves * kXchWave;   // floats
+    constexpr int kF = NETS * kFeatNet;
+    static_assert(kWaves == 4 && NETS * B2 * B1 == 8 && NETS * B1 == 4, "four quarters of two dW2 blocks and one dW1 block each");
+    static_assert(kXch + kWaves * kScalars + kWaves * kF <= Im::kTotal, "the exchange fits into the images + staging areas");
+    float* reds = lds + kXch;                      // [kWaves][kScalars]
+    float* fr = reds + kWaves * kScalars;          // [kWaves][net][5][64]
     float* out = partial + (int64_t)blockIdx.x * kPartial;
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        float v = sc[k];
+    for (int off = 32; off > 0; off >>= 1) {       // level by level: the 11 exchanges of a level are independent (sum by sum they were 66 dependent LDS round trips)
+        float o[11];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) reds[wave * kScalars + k] = v;
+        for (int k = 0; k < 11; ++k) o[k] = __shfl_xor(sc[k], off);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) sc[k] += o[k];
     }
-    __syncthreads();
-    if (tid < kScalars) reds[tid] = (tid < 11) ? (reds[tid] + reds[kScalars + tid]) + (reds[2 * kScalars + tid] + reds[3 * kScalars + tid]) : 0.0f;
-    __syncthreads();
-    if (tid < kScalars) out[kOffScal + tid] = reds[tid];
-    {   // per-feature sums: [kWaves][net][5][64] behind the scalars, then one thread per entry adds the four waves
-        constexpr int kF = NETS * kFeatNet;
-        float* fr = lds + kWaves * kScalars;
+    if (lane < 11) {
+        float v = sc[0];
 #pragma unroll
-        for (int ni = 0; ni < NETS; ++ni) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o) fr[wave * kF + ni * kFeatNet + o * 64 + lane] = f_w3[ni][o];
-            fr[wave * kF + ni * kFeatNet + 4 * 64 + lane] = f_b2[ni];
-        }
-        __syncthreads();
-        for (int e = tid; e < kF; e += kBlock) out[kOffFeat + e] = (fr[e] + fr[kF + e]) + (fr[2 * kF + e] + fr[3 * kF + e]);
+        for (int k = 1; k < 11; ++k) v = (lane == k) ? sc[k] : v;
+        reds[wave * kScalars + lane] = v;
     }
-    // Blocks: every wave writes its accumulator block to its own LDS slab in canonical [m][n] order (the staging areas are
-    // free now: four blocks fit into each), then the workgroup adds the four slabs in a fixed order -- no atomics (a float
-    // atomicAdd on LDS compiles to a compare-and-swap loop without unsafe-fp-atomics: 5.8 us per block, measured), and the
-    // sum does not depend on timing.
-    float* slab = lds + Im::kImage + wave * Im::kStage;
-    auto put = [&](const f32x16& acc, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[slot * 1024 + rowmap(r, h) * 32 + col] = acc[r];
-    };
-    auto drain = [&](int first_blk, int n_blk) __attribute__((always_inline)) {
-        __syncthreads();
-        for (int e = tid; e < n_blk * 1024; e += kBlock) {
-            const float* p0 = lds + Im::kImage + e;
-            out[first_blk * 1024 + e] = (p0[0] + p0[Im::kStage]) + (p0[2 * Im::kStage] + p0[3 * Im::kStage]);
+    for (int ni = 0; ni < NETS; ++ni) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) fr[wave * kF + ni * kFeatNet + o * 64 + lane] = f_w3[ni][o];
+        fr[wave * kF + ni * kFeatNet + 4 * 64 + lane] = f_b2[ni];
+    }
+    auto quarter = [&](int q, int v4) __attribute__((always_inline)) -> f32x4 {   // float4 v4 of quarter q of this wave's accumulators
+        if (v4 < 8) {
+            const f32x16& b = acc[2 * q + (v4 >> 2)];
+            const int r = 4 * (v4 & 3);
+            return f32x4{b[r], b[r + 1], b[r + 2], b[r + 3]};
         }
-        __syncthreads();
+        return acc1[q][v4 - 8];
     };
-    static_assert(Im::kStage >= 4 * 1024, "a wave's staging area holds four accumulator blocks");
+    f32x4* xch = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q != wave) {
+            const int slot = (q < wave) ? q : q - 1;
+#pragma unroll
+            for (int v4 = 0; v4 < 10; ++v4) xch[((wave * 3 + slot) * 10 + v4) * 64 + lane] = quarter(q, v4);
+        }
+    }
+#if defined(R6U_STAMPS) && R6U_STAMP_SET == 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint64_t tsb = wall_clock64();
+#endif
     __syncthreads();
-    // dW1's 16 x 16 blocks go into the left half of a 32 x 32 slot (the right half, never read, is zeroed)
-    auto put16 = [&](const f32x4 (&a2x)[2], int slot) __attribute__((always_inline)) {
+#if defined(R6U_STAMPS) && R6U_STAMP_SET == 2
+    const uint64_t tsc = wall_clock64();
+#endif
+    if (tid < kScalars) out[kOffScal + tid] = (tid < 11) ? (reds[tid] + reds[kScalars + tid]) + (reds[2 * kScalars + tid] + reds[3 * kScalars + tid]) : 0.0f;
+    for (int e = tid; e < kF; e += kBlock) out[kOffFeat + e] = (fr[e] + fr[kF + e]) + (fr[2 * kF + e] + fr[3 * kF + e]);
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
+    for (int q = 0; q < 4; ++q) {
+        if (q == wave) {
+            f32x4 part[10][4];                     // all 30 reads first, in one go: read-add-store group by group was ten exposed LDS round trips
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m2 * 16 + 4 * (lane >> 4) + r;
-                slab[slot * 1024 + m * 32 + (lane & 15)] = a2x[m2][r];
-                slab[slot * 1024 + m * 32 + 16 + (lane & 15)] = 0.0f;
+            for (int v4 = 0; v4 < 10; ++v4) {
+#pragma unroll
+                for (int src = 0; src < 4; ++src) {
+                    if (src != q) part[v4][src] = xch[((src * 3 + ((q < src) ? q : q - 1)) * 10 + v4) * 64 + lane];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v4 = 0; v4 < 10; ++v4) {
+                part[v4][q] = quarter(q, v4);
+                const f32x4 tot = (part[v4][0] + part[v4][1]) + (part[v4][2] + part[v4][3]);
+                if (v4 < 8) {   // dW2 block 2q + v4 / 4 in the partial set's net-major order (per net: dW2 [mb][ib], then dW1 [ib])
+                    const int ai = 2 * q + (v4 >> 2), blk = (ai / (B2 * B1)) * kNetBlocks + ai % (B2 * B1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[blk * 1024 + rowmap(4 * (v4 & 3) + i, h) * 32 + col] = tot[i];
+                } else {        // dW1's 16 x 16 blocks: the left half of a 32 x 32 slot (the right half is never read)
+                    const int blk = (q / B1) * kNetBlocks + B2 * B1 + q % B1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[blk * 1024 + ((v4 - 8) * 16 + 4 * (lane >> 4) + i) * 32 + (lane & 15)] = tot[i];
+                }
             }
         }
-    };
-    // the 12 blocks in their net-major order (per net: dW2 [mb][ib], then dW1 [ib]), four per round
-    static_assert(kNumBlocks % 4 == 0, "whole rounds");
-#pragma unroll
-    for (int round = 0; round < kNumBlocks / 4; ++round) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int blk = round * 4 + k, ni = blk / kNetBlocks, loc = blk % kNetBlocks;
-            if (loc < B2 * B1) put(acc[ni * B2 * B1 + loc], k);
-            else put16(acc1[ni * B1 + (loc - B2 * B1)], k);
-        }
-        drain(round * 4, 4);
     }
 #ifdef R6U_STAMPS
     if (tid == 0) {   // 100 MHz ticks: staging, tile loop of wave 0, reduction
+#if R6U_STAMP_SET == 1     // staging: parameter loads issued | the first tile's loads issued | everything arrived | LDS writes + barrier
+        out[kOffScal + 12] = (float)(tsa - ts0);
+        out[kOffScal + 13] = (float)(tsb - tsa);
+        out[kOffScal + 14] = (float)(tsc - tsb);
+        out[kOffScal + 15] = (float)(ts1 - tsc);
+#elif R6U_STAMP_SET == 2   // reduction: first barrier | shuffles + exchange writes | second barrier | sums + stores issued
+        out[kOffScal + 12] = (float)(tsa - ts2);
+        out[kOffScal + 13] = (float)(tsb - tsa);
+        out[kOffScal + 14] = (float)(tsc - tsb);
+        out[kOffScal + 15] = (float)(wall_clock64() - tsc);
+#else
         out[kOffScal + 12] = (float)(ts1 - ts0);
         out[kOffScal + 13] = (float)(ts2 - ts1);
         out[kOffScal + 14] = (float)(wall_clock64() - ts2);
+#endif
     }
     if (tid < kStampSlots && blockIdx.x == 0) {   // differences to the tile's first stamp, behind the last workgroup's partial set
         const uint32_t t0 = __float_as_uint(lds[Im::kTotal]), tk = __float_as_uint(lds[Im::kTotal + tid]);
@@ -865,7 +1122,9 @@ __global__ __launch_bounds__(1024) void ppo_grad_reduce_kernel(const float* __re
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
     float v = 0.0f;
-    if (e < kPartial) {
+    // the right half of a dW1 slot (a 16-wide block in a 32-wide slot) is never written: a sixth of a partial set that is not read
+    const bool unused = e < kNumBlocks * 1024 && ((e >> 10) % (B2 * B1 + B1)) >= B2 * B1 && (e & 31) >= 16;
+    if (e < kPartial && !unused) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int s = w;
         for (; s + 7 * kW < n_sets; s += 8 * kW) {
