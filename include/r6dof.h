@@ -47,7 +47,7 @@ enum { R6_SHAPING_ACCELERATION = 0, R6_SHAPING_VELOCITY = 1 };
 enum { R6_REWARD_STANDARD = 0, R6_REWARD_ANNEALED = 1 };
 /* bits of R6Buffers.flags[i] */
 enum { R6_FLAG_GROUND = 1, R6_FLAG_BOUNDS = 2, R6_FLAG_TRUNCATED = 4 };
-enum { R6_E_BADARG = -10001, R6_E_ALIGN = -10002 };
+enum { R6_E_BADARG = -10001, R6_E_ALIGN = -10002, R6_E_DEVICE = -10003 /* a kernel of an earlier call reported a failed launch-internal wait: see r6_step_k */ };
 /* columns of R6Buffers.stats */
 #define R6_NUM_STATS 8
 enum {
@@ -176,7 +176,10 @@ int r6_step(const R6Params *params, const R6Buffers *buf, uint64_t seed, uint64_
  * (stride 0: all steps write the same buffer, as K r6_step calls on one R6Buffers would):
  *   action (k,n,3) in;  obs (k,n,obs_dim), reward (k,n), done (k,n), flags (k,n), nfev (k,n), terms (k,8,ld),
  *   final_obs (k,n,obs_dim), fin_return / fin_length (k,n) out.
- * state, epconst, ep_step, ep_return, stats are the same single arrays as in r6_step (read before / written after). */
+ * state, epconst, ep_step, ep_return, stats are the same single arrays as in r6_step (read before / written after).
+ * Batches of at most one 64-env tile per SIMD run as two kinds of waves per tile (dynamics / reward) that hand each other
+ * work through LDS; their waits are bounded, and a wait that ever ran out is reported by the NEXT r6_step_k call of the
+ * process as R6_E_DEVICE (sticky: the stepped envs are in an unknown state) -- never silently. */
 enum { R6_K_LAST_ONLY = 1 /* only the last step's per-step outputs are stored (throughput rollouts, burn-in) */ };
 typedef struct R6StepK {
     int32_t k;                /* env steps in this launch, 1..65536 */

@@ -1082,6 +1082,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
 // Every wait is bounded: a wave that does not see its partner's counter move for ~0.1 s raises the workgroup's abort word and
 // both leave (outputs then incomplete -- a partner that never arrives means the launch was broken anyway); the grid always drains.
 // -------------------------------------------------------------------------------------------------
+#ifndef R6_PAIR_SPIN_LOG2
+#define R6_PAIR_SPIN_LOG2 21   // polls of a bounded wait (about 0.1 s); a dev build with 3 provokes the abort path (scripts/stepk_abort_check.py)
+#endif
 #ifndef R6_PAIR_RING
 #define R6_PAIR_RING 4
 #endif
@@ -1096,7 +1099,7 @@ static_assert(kRing >= 2 * kPairNB, "the ring holds at least two steps per rewar
 typedef __attribute__((address_space(3))) int* lds_word_t;
 __device__ __forceinline__ bool pair_wait(lds_word_t counter, int need, lds_word_t abort_word) {
 #pragma unroll 1
-    for (int spin = 0; spin < (1 << 21); ++spin) {
+    for (int spin = 0; spin < (1 << R6_PAIR_SPIN_LOG2); ++spin) {
         const int v = __builtin_amdgcn_readfirstlane(__atomic_load_n(counter, __ATOMIC_RELAXED));
         if (v >= need) return true;
         if (__builtin_amdgcn_readfirstlane(__atomic_load_n(abort_word, __ATOMIC_RELAXED)) != 0) return false;
@@ -1108,7 +1111,7 @@ __device__ __forceinline__ bool pair_wait(lds_word_t counter, int need, lds_word
 
 template <int INTEG, int SHAPING, int OD>
 __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Params p, const R6Buffers b, const R6StepK sk, const uint64_t seed,
-                                                                    const uint64_t step_index, const uint64_t env_offset) {
+                                                                    const uint64_t step_index, const uint64_t env_offset, int* host_abort) {
     static_assert(INTEG == R6_EULER || INTEG == R6_RK4, "fixed-step integrators (one sub-step per env step)");
     __shared__ float ring[kPairTiles][kRing][kSlotWords][64];
     __shared__ float ep_run[kPairTiles][64];                               // running episode return of a tile's envs, handed from reward wave to reward wave
@@ -1407,6 +1410,9 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     __syncthreads();
     if (b.stats && tid < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] != 0ull)
         b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
+    // an abort leaves this workgroup's outputs incomplete: say so where the host sees it (a word of mapped host memory, read
+    // by the next r6_step_k call and by r6_last_error) -- never silently
+    if (tid == 0 && host_abort && abort_word != 0) __hip_atomic_store(host_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1754,6 +1760,42 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     launch_step_one<INTEG, SHAPING, OD>(p, b, seed, step, off, s, R6_MAX_BLOCKS, true);
 }
 
+// The word step_k_pair_kernel raises when one of its bounded waits ran out: mapped host memory, allocated at the first launch
+// outside a stream capture (an allocation would break the capture; a launch captured before any eager one runs without the word).
+static std::atomic<int*> g_pair_abort_host{nullptr};
+static std::atomic<int*> g_pair_abort_dev{nullptr};
+static int* pair_abort_word(hipStream_t s) {
+    int* d = g_pair_abort_dev.load(std::memory_order_acquire);
+    if (d) return d;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    d = g_pair_abort_dev.load(std::memory_order_acquire);
+    if (d) return d;
+    int* h = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess || !h) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    *h = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return nullptr;
+    }
+    g_pair_abort_host.store(h, std::memory_order_release);
+    g_pair_abort_dev.store(d, std::memory_order_release);
+    return d;
+}
+static bool pair_abort_raised() {
+    int* h = g_pair_abort_host.load(std::memory_order_acquire);
+    return h && *reinterpret_cast<volatile int*>(h) != 0;
+}
+
 template <int INTEG, int SHAPING, int OD>
 void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
     if constexpr (INTEG != R6_RK45) {
@@ -1766,7 +1808,8 @@ void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk
             if (blocks > R6_MAX_BLOCKS) blocks = R6_MAX_BLOCKS;
             R6StepK skl = sk;
             skl.flags = sk.flags & ~R6_K_DIRECT_OBS_INTERNAL;
-            hipLaunchKernelGGL((r6::step_k_pair_kernel<INTEG, SHAPING, OD>), dim3((unsigned)blocks), dim3(r6::kPairBlock), 0, s, p, b, skl, seed, step, off);
+            hipLaunchKernelGGL((r6::step_k_pair_kernel<INTEG, SHAPING, OD>), dim3((unsigned)blocks), dim3(r6::kPairBlock), 0, s, p, b, skl, seed, step, off,
+                               pair_abort_word(s));
             return;
         }
     }
@@ -1868,6 +1911,9 @@ int r6_step_k(const R6Params* params, const R6Buffers* buf, const R6StepK* steps
               uint64_t env_offset, void* stream) {
     if (int rc = validate_common(params, buf)) return rc;
     if (!steps) return fail(R6_E_BADARG, "r6_step_k: null R6StepK");
+    if (pair_abort_raised())
+        return fail(R6_E_DEVICE, "r6_step_k: an earlier launch of this process gave up a bounded wait between the waves of a workgroup "
+                                 "(step_k_pair_kernel): its outputs are incomplete and the envs it stepped are in an unknown state");
     const R6Buffers& b = *buf;
     const R6StepK& sk = *steps;
     if (sk.k < 1 || sk.k > 65536) return fail(R6_E_BADARG, "r6_step_k: k must be in 1..65536");
