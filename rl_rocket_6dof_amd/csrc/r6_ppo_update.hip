@@ -65,7 +65,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Every layer product of the kernel except dW1 can run as v_mfma_f32_32x32x16_f16 on f16 hi + lo splits of both operands (three or
 // four products per K-step of 16, fp32 accumulation; the scheme of r6_policy.hip) instead of v_mfma_f32_32x32x2_f32 -- 1/16 of the
 // matrix time per K for 3-4x the instructions:
-//   R6U_F16_FWD   forward layers 1 and 2 (B operand = an activation block in accumulator layout), all four partial products;
+//   R6U_F16_FWD   forward layers 1 and 2 (B operand = an activation block in accumulator layout);
 //   R6U_F16_BWD   the delta1 chains; delta2 is scaled per tile by a power of two first (gradients carry 1 / n and have any magnitude);
 //   R6U_F16_DW2   dW2 = delta2 a1^T (contraction over the samples), the scaled delta2 again: a tile's products are summed in a block
 //                 of their own and join the launch's sums times the inverse factor.
@@ -76,7 +76,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // torch's own fp32 autograd (scripts/ppo_grad_accuracy.py: worst gradient entry 0.5-3.6e-6 of its tensor's largest, torch fp32
 // 0.5e-6-1.5e-5, exact-fp32 kernel 0.5-6.7e-6).  Measured on MI355X (scripts/ppo_grad_ab.py, 65 536 samples, gradient + reduce
 // launches): exact fp32 everywhere 63.4 us; delta1 chains in f16 58.2; + this round's staging / end-of-launch reduction 50.6;
-// + f16 forward 45.9; + f16 dW2 42.6 us (two (64, 64) MLPs: 67.4 -> 50.3).  dW1 (16x16x4 fp32, 2048 cycles of a tile) stays exact:
+// + f16 forward 45.9 (all four partial products; three: 45.0, the default -- lo * lo is below what the split itself keeps);
+// + f16 dW2 42.6 us with four, 41.8 with three forward products (two (64, 64) MLPs: 67.4 -> 50.3).  dW1 (16x16x4 fp32, 2048 cycles of a tile) stays exact:
 // delta1 has no cheap bound for an f16 scale.  All three default to 1; =0 gives the exact-fp32 forms back.
 #ifndef R6U_F16_FWD
 #define R6U_F16_FWD 1
@@ -122,9 +123,8 @@ __device__ __forceinline__ Split split8(const float (&x)[8]) {
     }
     return s;
 }
-// acc += A * B with all four partial products: the forward pass uses this form -- everything downstream (the loss gradient g, and
-// with it every parameter gradient, among them bias gradients that are cancelled sums over the samples) inherits the forward's
-// error, and lo * lo (2^-22 of a product) is the largest term the three-product form drops; a fourth f16 MFMA costs 32 cycles
+// acc += A * B with all four partial products (-DR6U_FWD_MFMA=mfma4: the forward's error reaches every gradient through the loss,
+// and lo * lo, 2^-22 of a product, is the largest term the three-product form drops; the fourth f16 MFMA costs 32 cycles)
 __device__ __forceinline__ f32x16 mfma4(const h8& ah, const h8& al, const Split& b, f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b.hi, acc, 0, 0, 0);
@@ -139,7 +139,7 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
 }
 
 #ifndef R6U_FWD_MFMA
-#define R6U_FWD_MFMA mfma4
+#define R6U_FWD_MFMA mfma3   // mfma4 adds lo * lo: 0.8 us per 65 536-sample launch for no measurable accuracy (scripts/ppo_grad_accuracy.py)
 #endif
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -1395,8 +1395,7 @@ __global__ __launch_bounds__(1024) void adam_clip_small_kernel(float* __restrict
                                                                const float* __restrict__ lr_dev, const float beta1, const float beta2,
                                                                const float eps, int64_t* __restrict__ step_dev, const int clamp_off,
                                                                const int clamp_n, const float clamp_min) {
-    __shared__ double red[16];
-    __shared__ float coef_s;
+    __shared__ float red[16];
     float g[K], mm[K], vv[K], pp[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -1409,23 +1408,25 @@ __global__ __launch_bounds__(1024) void adam_clip_small_kernel(float* __restrict
     }
     const int64_t t = *step_dev + 1;                       // torch.optim.Adam: step count starts at 1
     const float lr = lr_dev ? *lr_dev : lr_value;
-    double ss = 0.0;
+    // the norm as torch forms it (fp32 squares): a lane's K squares and the wave's sum in fp32, the 16 wave sums in double by
+    // EVERY thread after one barrier -- no serial section of one thread, no second barrier (round 2: double shuffles, thread 0
+    // adding and taking a double square root between two barriers: 8.4 us per step for 10 311 parameters)
+    float ss = 0.0f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) ss += (double)g[k] * (double)g[k];
+    for (int k = 0; k < K; ++k) ss = fmaf(g[k], g[k], ss);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    // the bias corrections meanwhile: beta^t = 2^(t log2 beta) on the transcendental unit
+    const float tf = (float)t;
+    const float bc1 = 1.0f - __builtin_amdgcn_exp2f(tf * __log2f(beta1)), bc2 = 1.0f - __builtin_amdgcn_exp2f(tf * __log2f(beta2));
+    const float step_size = lr / bc1, isq_bc2 = __builtin_amdgcn_rsqf(bc2);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int k = 0; k < 16; ++k) tot += red[k];
-        const float total_norm = (float)sqrt(tot);
-        coef_s = (max_norm > 0.0f) ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;   // clip_grad_norm_: clamped to 1
-    }
-    __syncthreads();
-    const float coef = coef_s;
-    const float bc1 = 1.0f - powf(beta1, (float)t), bc2 = 1.0f - powf(beta2, (float)t);
-    const float step_size = lr / bc1, isq_bc2 = 1.0f / sqrtf(bc2);
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += (double)red[k];
+    const float total_norm = sqrtf((float)tot);
+    const float coef = (max_norm > 0.0f) ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;   // clip_grad_norm_: clamped to 1
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int i = k * 1024 + threadIdx.x;
