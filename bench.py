@@ -415,6 +415,46 @@ def side_measurement(torch, dev, cfg, *, n, integrator, dt, k, pool_count, burni
     return out
 
 
+def ppo_side_measurement(torch, dev, iters: int = 5, warm: int = 3) -> dict:
+    """SURVEY section 8 (f2), the loop main_6DOF.py:107-139 drives through SB3: PPO iterations of the on-device trainer at the
+    configuration of examples/train_ppo.py -- rollout + GAE, then 10 epochs x 16 minibatch steps -- timed whole (wall clock around
+    synchronised iterations).  A side figure of the line, never its `value`; an exception is reported, not raised."""
+    import time
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+    from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+    n, steps = 16384, 64
+    out = {"workload": "PPO on 16 384 wrapped envs (remove-mass obs, reward clip, 1500-step limit) x 64 steps per rollout, shared tanh trunk "
+                       "[128, 64], 10 epochs x 16 minibatches of 65 536 samples, random initial weights"}
+    try:
+        env = BatchedRocket6DOF(n, default_env_config(), remove_mass=True, clip_reward=(-1, 100), max_episode_steps=1500, seed=1, device=dev)
+        algo = PPO(env, PPOConfig(n_steps=steps, batch_size=1 << 16, net_arch=(128, 64), shared_trunk=True, log_std_min=-2.5))
+        for _ in range(warm):
+            algo.collect_rollouts()
+            algo.train()
+        torch.cuda.synchronize()
+        roll = upd = 0.0
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            algo.collect_rollouts()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            algo.train()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            roll += t1 - t0
+            upd += t2 - t1
+        roll, upd = roll / iters, upd / iters
+        out.update({"env_steps_per_s": steps * n / (roll + upd), "rollout_and_gae_ms": roll * 1e3, "update_ms": upd * 1e3,
+                    "minibatch_step_us": upd / 160 * 1e6, "iterations_timed": iters})
+        del algo, env
+        torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001 -- a side figure must not cost the line
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) -> dict:
     """The N > 1 record's second loop, itemised (rank-reduced with max over ranks):
       first_gather_us   the very first all-gather of the process (communicator creation, buffer registration) timed alone,
@@ -588,6 +628,7 @@ def main(argv=None):
                     torch, dev, cfg, n=65536, integrator="euler", dt=0.04, k=16, pool_count=2, burnin=2000, steps=8000,
                     warmup=800, label="BASELINE configs[1]: 65 536 envs, Euler dt 0.04, r6_step_k with 16 steps per launch, "
                                       "all per-step outputs stored")}
+            extras["ppo_training"] = ppo_side_measurement(torch, dev)
         if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:
             extras["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         line = build_line(args, world, n, dt, wall, kernel_ms, traffic=traffic, traffic_source=source, extras=extras)
