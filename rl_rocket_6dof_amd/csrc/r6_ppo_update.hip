@@ -138,6 +138,9 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
 }
 
+#ifndef R6U_ABLATE
+#define R6U_ABLATE 0   // dev: leave out 1 = the dW3 sums, 2 = the dW1 products, 4 = the db2 row sums (timing only: wrong gradients)
+#endif
 #ifndef R6U_FWD_MFMA
 #define R6U_FWD_MFMA mfma3   // mfma4 adds lo * lo: 0.8 us per 65 536-sample launch for no measurable accuracy (scripts/ppo_grad_accuracy.py)
 #endif
@@ -794,7 +797,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             }
             wave_sync();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < ((R6U_ABLATE & 1) ? 0 : 8); ++q) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             {
                 float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < ((R6U_ABLATE & 4) ? 0 : 8); ++q) {
                     const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
                     rs[0] += dv[0];
                     rs[1] += dv[1];
@@ -972,7 +975,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     ldv<8>(tr4_base + Im::sBlk, t0);
                     ldv<8>(tr4_base + Im::sBlk + 16 * kPitch, t1);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < ((R6U_ABLATE & 2) ? 0 : 8); ++j) {
                         acc1[ni * B1 + ib][0] = mfma16(t0[j], bxc[j], acc1[ni * B1 + ib][0]);
                         acc1[ni * B1 + ib][1] = mfma16(t1[j], bxc[j], acc1[ni * B1 + ib][1]);
                     }
