@@ -138,6 +138,9 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b.hi, acc, 0, 0, 0);
 }
 
+#ifndef R6U_SCHED
+#define R6U_SCHED 0   // dev: scheduling experiments (bit mask)
+#endif
 #ifndef R6U_ABLATE
 #define R6U_ABLATE 0   // dev: leave out 1 = the dW3 sums, 2 = the dW1 products, 4 = the db2 row sums (timing only: wrong gradients)
 #endif
@@ -149,6 +152,26 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __bu
 // 16 x 16 output, K = 4 per instruction (lane l: A row / B column l % 16, k = l / 16; D register r: row 4 (l / 16) + r, column l % 16):
 // the shape of dW1 = delta1 x^T, whose 14 + 1 useful columns fill a 16-wide block where the 32-wide one was half padding
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// tanh of an accumulator block, stage by stage over groups of eight: a value that comes off the transcendental unit cannot be
+// used by the very next instruction (the compiler pads with s_nop), and element by element -- the order the scheduler kept for
+// a block that sits in accumulation registers -- every exp and every rcp was followed by such a bubble (192 per tile)
+__device__ __forceinline__ void tanh_block(const f32x16& z, f32x16& a) {
+#pragma unroll
+    for (int g8 = 0; g8 < 16; g8 += 8) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = kExpScale * z[g8 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(e[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] += 1.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[g8 + j] = fmaf(-2.0f, e[j], 1.0f);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 // tanh(z) = 1 - 2 / (exp(2z) + 1): v_exp_f32 + v_rcp_f32, absolute error ~1e-7, saturates cleanly
 __device__ __forceinline__ float tanh_fast(float z) {
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(kExpScale * z) + 1.0f), 1.0f);
@@ -652,7 +675,9 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 z = R6U_FWD_MFMA(frag[f], frag[f + Im::kFrag / 4], xs, z);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[ni][blk][r] = tanh_fast(z[r]);
+#if !(R6U_SCHED & 1)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             f32x16 z2[B2];
 #pragma unroll
@@ -675,15 +700,16 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                         const int f = (Im::oW2 + ((((ni * B2 + mb) * B1 + b) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
                         z2[mb] = R6U_FWD_MFMA(frag[f], frag[f + Im::kFrag / 4], bs, z2[mb]);
                     }
+#if !(R6U_SCHED & 2)
                     asm volatile("" ::: "memory");   // keeps the scheduler from hoisting every group's LDS reads up front
+#endif
                 }
+#if !(R6U_SCHED & 4)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
 #pragma unroll
-            for (int mb = 0; mb < B2; ++mb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a2[ni][mb][r] = tanh_fast(z2[mb][r]);
-            }
+            for (int mb = 0; mb < B2; ++mb) tanh_block(z2[mb], a2[ni][mb]);
         }
 #else
 #pragma unroll
@@ -732,16 +758,30 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int ni = 0; ni < NETS; ++ni) {
+            // LDS operands in batches: all 16 rows of a block are requested before the first is used, the next block's while this
+            // one's FMAs issue -- read-use-read-use exposed an LDS round trip per row at one wave per SIMD (two thirds of the
+            // kernel's s_waitcnt sat within two instructions of their ds_read)
+            constexpr int kCh = 2 * B2;               // chunks of 8 rows (row = 16 mb + r)
+            f32x4 w3r[2][8];
 #pragma unroll
-            for (int mb = 0; mb < B2; ++mb) {
+            for (int j = 0; j < 8; ++j) w3r[0][j] = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + j * 4);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + (mb * 16 + r) * 4);
-                    part[0] = fmaf(w3[0], a2[ni][mb][r], part[0]);
-                    part[1] = fmaf(w3[1], a2[ni][mb][r], part[1]);
-                    part[2] = fmaf(w3[2], a2[ni][mb][r], part[2]);
-                    part[3] = fmaf(w3[3], a2[ni][mb][r], part[3]);
+            for (int c = 0; c < kCh; ++c) {
+                if (c + 1 < kCh) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w3r[(c + 1) & 1][j] = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + ((c + 1) * 8 + j) * 4);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float av = a2[ni][c >> 1][(c & 1) * 8 + j];
+                    part[0] = fmaf(w3r[c & 1][j][0], av, part[0]);
+                    part[1] = fmaf(w3r[c & 1][j][1], av, part[1]);
+                    part[2] = fmaf(w3r[c & 1][j][2], av, part[2]);
+                    part[3] = fmaf(w3r[c & 1][j][3], av, part[3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const float m0 = part[0] + __shfl_xor(part[0], 32) + b3_0;
@@ -796,25 +836,62 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 for (int r = 0; r < 16; ++r) tw_base[Im::sT2 + (mb * 32 + rowmap(r, 0)) * kPitch] = a2[ni][mb][r];
             }
             wave_sync();
+            if (!(R6U_ABLATE & 1)) {   // this lane's row of a2 (8 reads) and g's four rows (32 broadcast reads, two q at a time)
+                f32x4 av[8], gv[2][2][4];
 #pragma unroll
-            for (int q = 0; q < ((R6U_ABLATE & 1) ? 0 : 8); ++q) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
+                for (int q = 0; q < 8; ++q) av[q] = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + o_g + o * kPitch + 4 * q);
-                    f_w3[ni][o] = fmaf(av[0], gv[0], fmaf(av[1], gv[1], fmaf(av[2], gv[2], fmaf(av[3], gv[3], f_w3[ni][o]))));
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) gv[0][q][o] = *reinterpret_cast<const f32x4*>(lds + o_g + o * kPitch + 4 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (c + 1 < 4) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) gv[(c + 1) & 1][q][o] = *reinterpret_cast<const f32x4*>(lds + o_g + o * kPitch + 4 * (2 * (c + 1) + q));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const f32x4 a4 = av[2 * c + q];
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const f32x4 g4 = gv[c & 1][q][o];
+                            f_w3[ni][o] = fmaf(a4[0], g4[0], fmaf(a4[1], g4[1], fmaf(a4[2], g4[2], fmaf(a4[3], g4[3], f_w3[ni][o]))));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             R6U_MARK(3);   // dW3 sums (+ staging of a2)
             // ---- delta2 = (W3^T g) (1 - a2^2): this lane half's 16 rows per block ---------------------------------------------
             f32x16 d2[B2];
+            {
+                constexpr int kCh = 2 * B2;
+                f32x4 w3r[2][8];
 #pragma unroll
-            for (int mb = 0; mb < B2; ++mb) {
+                for (int j = 0; j < 8; ++j) w3r[0][j] = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + j * 4);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x4 w3 = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + (mb * 16 + r) * 4);
-                    const float up = fmaf(w3[0], g[0], fmaf(w3[1], g[1], fmaf(w3[2], g[2], w3[3] * g[3])));
-                    d2[mb][r] = up * fmaf(-a2[ni][mb][r], a2[ni][mb][r], 1.0f);
+                for (int c = 0; c < kCh; ++c) {
+                    if (c + 1 < kCh) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w3r[(c + 1) & 1][j] = *reinterpret_cast<const f32x4*>(w3_base + ni * (2 * B2 * 64) + ((c + 1) * 8 + j) * 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int mb = c >> 1, r = (c & 1) * 8 + j;
+                        const f32x4 w3 = w3r[c & 1][j];
+                        const float up = fmaf(w3[0], g[0], fmaf(w3[1], g[1], fmaf(w3[2], g[2], w3[3] * g[3])));
+                        d2[mb][r] = up * fmaf(-a2[ni][mb][r], a2[ni][mb][r], 1.0f);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             wave_sync();   // the dW3 sums' reads of the a2 tile are done: delta2 takes its place
@@ -827,13 +904,16 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
             // db2[f] += sum_s delta2[f][s]: lane = feature again, a row sum
             {
                 float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 dv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dv[q] = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < ((R6U_ABLATE & 4) ? 0 : 8); ++q) {
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(lds + o_fr + Im::sT2 + 4 * q);
-                    rs[0] += dv[0];
-                    rs[1] += dv[1];
-                    rs[2] += dv[2];
-                    rs[3] += dv[3];
+                    rs[0] += dv[q][0];
+                    rs[1] += dv[q][1];
+                    rs[2] += dv[q][2];
+                    rs[3] += dv[q][3];
                 }
                 f_b2[ni] += (rs[0] + rs[1]) + (rs[2] + rs[3]);
             }
@@ -942,12 +1022,22 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
 #if R6U_F16_BWD
+                {   // the block's eight fragments are requested in one go (read - wait - three MFMAs, four times over, exposed a round trip each)
+                    h8 wh[B2][2], wl[B2][2];
 #pragma unroll
-                for (int c = 0; c < B2; ++c) {
+                    for (int c = 0; c < B2; ++c) {
 #pragma unroll
-                    for (int sk = 0; sk < 2; ++sk) {
-                        const int f = (Im::oW2T + ((((ni * B1 + ib) * B2 + c) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
-                        d1 = mfma3(frag[f], frag[f + Im::kFrag / 4], d2s[c][sk], d1);
+                        for (int sk = 0; sk < 2; ++sk) {
+                            const int f = (Im::oW2T + ((((ni * B1 + ib) * B2 + c) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
+                            wh[c][sk] = frag[f];
+                            wl[c][sk] = frag[f + Im::kFrag / 4];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < B2; ++c) {
+#pragma unroll
+                        for (int sk = 0; sk < 2; ++sk) d1 = mfma3(wh[c][sk], wl[c][sk], d2s[c][sk], d1);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
