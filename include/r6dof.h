@@ -248,7 +248,7 @@ size_t r6_policy_net_size(void); /* sizeof(R6PolicyNet) */
  * does not depend on sharding; `deterministic` != 0 returns the mean action (`model.predict(...,
  * deterministic=True)`, montecarlo_script.py).  fp32-accurate arithmetic on the matrix cores: every fp32 operand is
  * split into an f16 hi + lo pair (v_mfma_f32_32x32x16_f16, three products per K-step, fp32 accumulation; agrees
- * with torch fp32 to 2e-5).
+ * with torch fp32 to 2e-5; |obs| and |weights| must stay below f16's 65504).
  *   step_base (device, [1], or NULL) is added to step_index inside the kernel (see R6Buffers.step_base: graph replays).
  *   row_flags [n] / flag_mask: when row_flags != NULL only 32-row tiles holding a row with (row_flags[i] & flag_mask) != 0
  *   are evaluated and written, the others are skipped without touching their outputs -- V(terminal observation) for the
@@ -313,7 +313,10 @@ int r6_ppo_loss_grad(const float *mean, const float *value, const float *log_std
 /* ---- the whole PPO minibatch step's gradient in one launch ---------------------------------------------------------
  * SB3 1.6 `PPO.train` per minibatch (stable_baselines3/ppo/ppo.py, behind main_6DOF.py:107-139): evaluate_actions on the
  * minibatch rows, the clipped-surrogate / value / entropy loss of r6_ppo_loss_grad, and loss.backward() through the
- * actor-critic -- forward, loss and backward fused, on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32).  Supported
+ * actor-critic -- forward, loss and backward fused, on the matrix cores with fp32 accuracy: the layer products run on f16
+ * hi + lo splits of both operands with fp32 accumulation (lo rounded to nearest; against float64 autograd the gradients are as
+ * close as torch's own fp32 autograd), dW1 on v_mfma_f32_16x16x4_f32.  The splits put the observations
+ * and the weights through f16: |obs|, |weights| must stay below 65504 (they are O(1) here: normalised observations).  Supported
  * nets (obs_dim 13 | 14): the reference's topology, ONE shared tanh trunk obs -> 128 -> 64 with a 3-output action head and a
  * value head (R6PolicyNet.shared = 1, hidden (128, 64)), and SB3's default, two separate tanh MLPs obs -> 64 -> 64
  * (shared = 0, hidden (64, 64); BASELINE configs[4] "SB3 PPO MLP(64,64)").
