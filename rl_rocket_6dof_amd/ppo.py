@@ -109,7 +109,7 @@ class _FusedPPOLoss(torch.autograd.Function):
 class FusedMinibatchGrad:
     """One SB3 ``PPO.train`` minibatch -- ``evaluate_actions``, the clipped-surrogate / value / entropy loss and
     ``loss.backward()`` -- as ONE HIP launch (``r6_ppo_minibatch_grad``, csrc/r6_ppo_update.hip): parameter gradients come out
-    on the matrix cores in exact fp32, no activation goes to HBM and the minibatch rows are picked by index (no gathered
+    on the matrix cores with fp32 accuracy (f16 hi + lo operand splits, fp32 accumulation), no activation goes to HBM and the minibatch rows are picked by index (no gathered
     copies).  Supported: the reference's topology, one shared tanh trunk obs -> 128 -> 64 with both heads on it
     (``ActorCritic(net_arch=(128, 64), shared_trunk=True)``), and SB3's default, two separate tanh MLPs obs -> 64 -> 64
     (``ActorCritic(net_arch=(64, 64), shared_trunk=False)``; BASELINE configs[4]).  The gradient tensors are persistent and
