@@ -1537,6 +1537,68 @@ __global__ __launch_bounds__(1024) void adam_clip_small_kernel(float* __restrict
     if (threadIdx.x == 0) *step_dev = t;
 }
 
+// The same step spread over ceil(n / 1024) workgroups: every workgroup forms the WHOLE norm itself (K gradient loads per thread,
+// the same fixed-order sums as above, so all workgroups get the same bits) and then updates its own 1024 elements -- one element
+// of m, v, param per thread instead of K: the loads and stores of the optimiser state, the longer part of the one-workgroup
+// form, run on ceil(n / 1024) CUs at once.  Nobody reads what another workgroup writes (gradients are read-only here).  The step
+// count is read and advanced without a second buffer: every workgroup adds 2^48 to the word (an arrival count in bits the step
+// never reaches) and takes the step from the value the add returned; the workgroup that arrives last knows every other has
+// read it and stores the new count, arrival bits cleared.
+template <int K>
+__global__ __launch_bounds__(1024) void adam_clip_wide_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                                                              float* __restrict__ v, const int n, const float max_norm, const float lr_value,
+                                                              const float* __restrict__ lr_dev, const float beta1, const float beta2,
+                                                              const float eps, int64_t* __restrict__ step_dev, const int clamp_off,
+                                                              const int clamp_n, const float clamp_min) {
+    constexpr unsigned long long kArrive = 1ull << 48;
+    __shared__ float red[16];
+    __shared__ unsigned long long old_s;
+    if (threadIdx.x == 0) old_s = atomicAdd(reinterpret_cast<unsigned long long*>(step_dev), kArrive);
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool in = i < n;
+    const int ii = in ? i : 0;
+    const float mi0 = m[ii], vi0 = v[ii], pi0 = param[ii];
+    float g[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int j = k * 1024 + threadIdx.x;
+        const float gj = grad[j < n ? j : 0];
+        g[k] = j < n ? gj : 0.0f;
+    }
+    const float lr = lr_dev ? *lr_dev : lr_value;
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ss = fmaf(g[k], g[k], ss);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    float gi = 0.0f;   // this thread's own gradient: element k * 1024 + threadIdx.x with k = blockIdx.x
+#pragma unroll
+    for (int k = 0; k < K; ++k) gi = (k == (int)blockIdx.x) ? g[k] : gi;
+    __syncthreads();
+    const unsigned long long old = old_s;
+    const int64_t t = (int64_t)(old & (kArrive - 1)) + 1;   // torch.optim.Adam: step count starts at 1
+    const float tf = (float)t;
+    const float bc1 = 1.0f - __builtin_amdgcn_exp2f(tf * __log2f(beta1)), bc2 = 1.0f - __builtin_amdgcn_exp2f(tf * __log2f(beta2));
+    const float step_size = lr / bc1, isq_bc2 = __builtin_amdgcn_rsqf(bc2);
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += (double)red[k];
+    const float total_norm = sqrtf((float)tot);
+    const float coef = (max_norm > 0.0f) ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;   // clip_grad_norm_: clamped to 1
+    if (in) {
+        gi *= coef;
+        const float mi = fmaf(beta1, mi0, (1.0f - beta1) * gi);
+        const float vi = fmaf(beta2, vi0, (1.0f - beta2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        float p = pi0 - step_size * mi / fmaf(sqrtf(vi), isq_bc2, eps);
+        if (i >= clamp_off && i < clamp_off + clamp_n) p = fmaxf(p, clamp_min);
+        param[i] = p;
+    }
+    if (threadIdx.x == 0 && (old >> 48) + 1 == gridDim.x) *step_dev = t;
+}
+
 }  // namespace r6u
 
 extern "C" int r6_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
@@ -1547,7 +1609,12 @@ extern "C" int r6_adam_clip_step(float* param, const float* grad, float* exp_avg
         return R6_E_BADARG;
     }
     constexpr int kSmall = 12;
-    if (n <= kSmall * 1024)
+    static const int wide = [] { const char* e = std::getenv("R6_ADAM_WIDE"); return e ? std::atoi(e) : 1; }();   // A/B: 0 = the one-workgroup form
+    if (n <= kSmall * 1024 && wide)
+        hipLaunchKernelGGL(r6u::adam_clip_wide_kernel<kSmall>, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                           param, grad, exp_avg, exp_avg_sq, (int)n, max_grad_norm, lr, lr_dev, beta1, beta2, eps, step_dev, (int)clamp_off,
+                           (int)clamp_n, clamp_min);
+    else if (n <= kSmall * 1024)
         hipLaunchKernelGGL(r6u::adam_clip_small_kernel<kSmall>, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), param, grad, exp_avg,
                            exp_avg_sq, (int)n, max_grad_norm, lr, lr_dev, beta1, beta2, eps, step_dev, (int)clamp_off, (int)clamp_n, clamp_min);
     else
