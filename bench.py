@@ -341,8 +341,8 @@ def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: floa
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_us": kernel_ms * 1e3 * max(args.k, 1), "kernel": kernel,
-                     "working_set_note": "189 B x 2^20 = 198 MB per launch fits the 256 MB Infinity Cache: see out_of_cache "
-                                         "for the same kernel against HBM proper" if n * bytes_per < 256e6 else None},
+                     "working_set_note": (f"{bytes_per:g} B x {n} envs = {n * bytes_per / 1e6:.0f} MB per launch fits the 256 MB Infinity "
+                                          "Cache: see out_of_cache for the same kernel against HBM proper") if n * bytes_per < 256e6 else None},
     }
     if extras:
         line.update(extras)
