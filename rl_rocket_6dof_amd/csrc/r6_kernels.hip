@@ -1777,7 +1777,7 @@ static int* pair_abort_word(hipStream_t s) {
     d = g_pair_abort_dev.load(std::memory_order_acquire);
     if (d) return d;
     int* h = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess || !h) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !h) {
         (void)hipGetLastError();
         return nullptr;
     }
