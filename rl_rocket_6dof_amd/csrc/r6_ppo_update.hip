@@ -139,7 +139,7 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
 }
 
 #ifndef R6U_SCHED
-#define R6U_SCHED 0   // dev: scheduling experiments (bit mask)
+#define R6U_SCHED 24   // software pipelines: 8 = layer 2 of the forward, 16 = the block loop of the backward (shared trunk only); 1, 2, 4: dev experiments
 #endif
 #ifndef R6U_ABLATE
 #define R6U_ABLATE 0   // dev: leave out 1 = the dW3 sums, 2 = the dW1 products, 4 = the db2 row sums (timing only: wrong gradients)
@@ -687,6 +687,56 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z2[mb][r] = zi[r];
             }
+#if R6U_SCHED & 8
+            {   // software pipeline over the 2 B1 K-steps: the next step's fragments are requested and its activations split while this
+                // step's six MFMAs run -- one MFMA, five vector instructions, in that order (a chain of MFMAs issued back to back
+                // holds the wave's issue for its whole duration, and the splits then run with the matrix pipe idle)
+                constexpr int kG = 2 * B1;
+                static_assert(R6U_F16_FWD, "f16 forward");
+                Split bs[2];
+                h8 wh[2][B2], wl[2][B2];
+                auto splitg = [&](int g) __attribute__((always_inline)) -> Split {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = a1[ni][g >> 1][(g & 1) * 8 + j];
+                    return split8(v);
+                };
+                auto loadg = [&](int g, h8 (&hh)[B2], h8 (&ll)[B2]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) {
+                        const int f = (Im::oW2 + ((((ni * B2 + mb) * B1 + (g >> 1)) * 2 + (g & 1)) * 2) * Im::kFrag) / 4 + lane;
+                        hh[mb] = frag[f];
+                        ll[mb] = frag[f + Im::kFrag / 4];
+                    }
+                };
+                loadg(0, wh[0], wl[0]);
+                bs[0] = splitg(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < kG; ++g) {
+                    if (g + 1 < kG) {
+                        loadg(g + 1, wh[(g + 1) & 1], wl[(g + 1) & 1]);
+                        bs[(g + 1) & 1] = splitg(g + 1);
+                    }
+                    // the three products of mfma3, the two blocks alternating: the same sums in the same order per accumulator
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) z2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[g & 1][mb], bs[g & 1].hi, z2[mb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) z2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g & 1][mb], bs[g & 1].lo, z2[mb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) z2[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[g & 1][mb], bs[g & 1].hi, z2[mb], 0, 0, 0);
+                    if (g + 1 < kG) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2 * B2, 0);
+#pragma unroll
+                        for (int i = 0; i < 3 * B2; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int b = 0; b < B1; ++b) {
 #pragma unroll
@@ -708,6 +758,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
+#endif
 #pragma unroll
             for (int mb = 0; mb < B2; ++mb) tanh_block(z2[mb], a2[ni][mb]);
         }
@@ -971,6 +1022,116 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 }
             }
 #endif
+#if R6U_F16_DW2
+            constexpr bool kPipeBlocks = (R6U_SCHED & 16) != 0 && NETS == 1;   // two MLPs: the pipelined form spills (11 registers) and loses
+#else
+            constexpr bool kPipeBlocks = false;
+#endif
+#if R6U_F16_DW2
+            if constexpr (kPipeBlocks) {
+            // The block loop as a software pipeline: matrix instructions and the vector work of the NEIGHBOURING stage alternate in
+            // program order (a wave issues in order: MFMAs back to back hold its issue for their whole duration, and the vector
+            // work then runs with the matrix pipe idle) --
+            //   B  the delta1 chain (12 MFMAs)            under  the split of the a1 block (dW2's B operand)
+            //   C  dW2's products (12 MFMAs, two chains)  under  delta1's scaling and tanh derivative
+            //   E  dW1's products (16 MFMAs, two chains)  under  adding dW2's products to the launch's sums
+            // Same operands, same order of sums per accumulator as the plain form (R6U_SCHED bit 16 off).
+#pragma unroll
+            for (int ib = 0; ib < B1; ++ib) {
+                wave_sync();   // the block buffer's previous readers are done
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw_base[Im::sBlk + rowmap(r, 0) * kPitch] = a1[ni][ib][r];
+                wave_sync();
+                // ---- A: requests
+                float ba[16];
+                ldv<16>(tr_base + Im::sBlk, ba);
+                h8 wh[B2][2], wl[B2][2];
+#pragma unroll
+                for (int c = 0; c < B2; ++c) {
+#pragma unroll
+                    for (int sk = 0; sk < 2; ++sk) {
+                        const int f = (Im::oW2T + ((((ni * B1 + ib) * B2 + c) * 2 + sk) * 2) * Im::kFrag) / 4 + lane;
+                        wh[c][sk] = frag[f];
+                        wl[c][sk] = frag[f + Im::kFrag / 4];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- B: delta1[i][s] = sum_f2 W2[f2][i] delta2[f2][s] (scaled), the a1 block split meanwhile: one MFMA of the chain,
+                //      one pair of the block split, fenced -- the group-barrier form of this stage came out as runs of MFMAs followed
+                //      by a run of 44 vector instructions
+                f32x16 d1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+                Split bas[2];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const int c = i / 6, sk = (i / 3) % 2, pr = i % 3;   // mfma3's order: lo * hi, hi * lo, hi * hi per (c, sk)
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pr == 0 ? wl[c][sk] : wh[c][sk], pr == 1 ? d2s[c][sk].lo : d2s[c][sk].hi, d1, 0, 0, 0);
+                    if (i < 8) {
+                        const int ss = i / 4, j = 2 * (i % 4);
+                        h2 hi2, lo2;
+                        split2(ba[8 * ss + j], ba[8 * ss + j + 1], hi2, lo2);
+                        bas[ss].hi[j] = hi2[0];
+                        bas[ss].hi[j + 1] = hi2[1];
+                        bas[ss].lo[j] = lo2[0];
+                        bas[ss].lo[j + 1] = lo2[1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- C: dW2's products of this tile (its own block: delta2 went in scaled), delta1 finished meanwhile
+                f32x16 part[B2];
+#pragma unroll
+                for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[mb][r] = 0.0f;
+                }
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {   // mfma3's three products, the two blocks alternating
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) part[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].lo, bas[sk].hi, part[mb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) part[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].hi, bas[sk].lo, part[mb], 0, 0, 0);
+#pragma unroll
+                    for (int mb = 0; mb < B2; ++mb) part[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].hi, bas[sk].hi, part[mb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1[r] = (d1[r] * d2_unscale) * fmaf(-a1[ni][ib][r], a1[ni][ib][r], 1.0f);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- D: delta1 takes the a1 block's place (its readers -- the request of stage A -- are done)
+                wave_sync();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw4_base[Im::sBlk + rowmap(r, 0) * kPitch] = d1[r];
+                wave_sync();
+                float t0[8], t1[8];
+                ldv<8>(tr4_base + Im::sBlk, t0);
+                ldv<8>(tr4_base + Im::sBlk + 16 * kPitch, t1);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- E: dW1[i][k] += sum_s delta1[i][s] x[k][s] (16x16x4, two row blocks), dW2's products join the launch's sums meanwhile
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc1[ni * B1 + ib][0] = mfma16(t0[j], bxc[j], acc1[ni * B1 + ib][0]);
+                    acc1[ni * B1 + ib][1] = mfma16(t1[j], bxc[j], acc1[ni * B1 + ib][1]);
+                }
+#pragma unroll
+                for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[iW2(ni, mb, ib)][r] = fmaf(part[mb][r], d2_unscale, acc[iW2(ni, mb, ib)][r]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            } else
+#endif
+            {
 #pragma unroll
             for (int ib = 0; ib < B1; ++ib) {
                 wave_sync();   // the block buffer's previous readers are done
@@ -1072,6 +1233,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 R6U_MARK(7 + 3 * ib);   // G1
+            }
             }
         }
         row_cur = row_next;
