@@ -139,7 +139,7 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const Split&
 }
 
 #ifndef R6U_SCHED
-#define R6U_SCHED 24   // software pipelines: 8 = layer 2 of the forward, 16 = the block loop of the backward (shared trunk only); 1, 2, 4: dev experiments
+#define R6U_SCHED 56   // software pipelines: 8 = layer 2 of the forward, 16 = the block loop of the backward (shared trunk only), 32 = layer 1; 1, 2, 4: dev experiments
 #endif
 #ifndef R6U_ABLATE
 #define R6U_ABLATE 0   // dev: leave out 1 = the dW3 sums, 2 = the dW1 products, 4 = the db2 row sums (timing only: wrong gradients)
@@ -155,22 +155,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 // tanh of an accumulator block, stage by stage over groups of eight: a value that comes off the transcendental unit cannot be
 // used by the very next instruction (the compiler pads with s_nop), and element by element -- the order the scheduler kept for
 // a block that sits in accumulation registers -- every exp and every rcp was followed by such a bubble (192 per tile)
+__device__ __forceinline__ void tanh_half(const f32x16& z, f32x16& a, const int g8) {
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = kExpScale * z[g8 + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(e[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] += 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[g8 + j] = fmaf(-2.0f, e[j], 1.0f);
+}
 __device__ __forceinline__ void tanh_block(const f32x16& z, f32x16& a) {
-#pragma unroll
-    for (int g8 = 0; g8 < 16; g8 += 8) {
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = kExpScale * z[g8 + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(e[j]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] += 1.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_rcpf(e[j]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[g8 + j] = fmaf(-2.0f, e[j], 1.0f);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    tanh_half(z, a, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    tanh_half(z, a, 8);
+    __builtin_amdgcn_sched_barrier(0);
 }
 // tanh(z) = 1 - 2 / (exp(2z) + 1): v_exp_f32 + v_rcp_f32, absolute error ~1e-7, saturates cleanly
 __device__ __forceinline__ float tanh_fast(float z) {
@@ -666,6 +668,40 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         const Split xs = split8(xk);
 #pragma unroll
         for (int ni = 0; ni < NETS; ++ni) {
+#if R6U_SCHED & 32
+            {   // layer 1 as a pipeline as well: all fragments requested at once, block b + 1's three MFMAs between the halves of block b's tanh
+                h8 w1h[B1], w1l[B1];
+#pragma unroll
+                for (int blk = 0; blk < B1; ++blk) {
+                    const int f = (Im::oW1 + (ni * B1 + blk) * 2 * Im::kFrag) / 4 + lane;
+                    w1h[blk] = frag[f];
+                    w1l[blk] = frag[f + Im::kFrag / 4];
+                }
+                f32x16 zc, zn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zc[r] = 0.0f;
+                zc = mfma3(w1h[0], w1l[0], xs, zc);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int blk = 0; blk < B1; ++blk) {
+                    if (blk + 1 < B1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zn[r] = 0.0f;
+                        zn = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[blk + 1], xs.hi, zn, 0, 0, 0);
+                        tanh_half(zc, a1[ni][blk], 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        zn = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[blk + 1], xs.lo, zn, 0, 0, 0);
+                        tanh_half(zc, a1[ni][blk], 8);
+                        __builtin_amdgcn_sched_barrier(0);
+                        zn = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[blk + 1], xs.hi, zn, 0, 0, 0);
+                        zc = zn;
+                    } else {
+                        tanh_block(zc, a1[ni][blk]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int blk = 0; blk < B1; ++blk) {
                 f32x16 z;
@@ -679,6 +715,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
+#endif
             f32x16 z2[B2];
 #pragma unroll
             for (int mb = 0; mb < B2; ++mb) {
