@@ -11,7 +11,7 @@ src, pmc, dst = (os.path.join(ROOT, "gpurun_out", f"profile_{tag}"), os.path.joi
                  os.path.join(ROOT, "profiles"))
 summ = json.load(open(os.path.join(src, "summary.json")))
 json.dump(summ, open(os.path.join(dst, f"{tag}_rocprofv3_summary.json"), "w"), indent=1)
-ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+ks = max(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # gpurun_out/ keeps earlier runs: the newest one
 shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench_under_trace.log")) if l.startswith("{")]
 if line:
