@@ -1852,6 +1852,14 @@ extern "C" {
 
 // shared with r6_policy.hip (not part of the public header)
 void r6_internal_set_error(const char* what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
+// test hook (tests/test_gpu_step_k.py; not part of the public header): sets (1) or clears (0) the word step_k_pair_kernel raises
+// when a bounded wait ran out, as a kernel would; returns 0 when the word does not exist yet (no pair launch so far).
+int r6_internal_test_pair_abort(int raise) {
+    int* h = g_pair_abort_host.load(std::memory_order_acquire);
+    if (!h) return 0;
+    *reinterpret_cast<volatile int*>(h) = raise ? 1 : 0;
+    return 1;
+}
 size_t r6_policy_net_size(void) { return sizeof(R6PolicyNet); }
 
 int r6_abi_version(void) { return R6_ABI_VERSION; }

@@ -157,3 +157,31 @@ def test_last_only_and_bad_arguments(cfg):
     assert b.lib.r6_step_k(C.byref(b.params), C.byref(b._buf), C.byref(sk), 0, 1, 0, None) == -10001
     with pytest.raises(ValueError):
         b.step_k(torch.zeros((0, 100, 3), device=b.device))
+
+
+def test_a_failed_launch_internal_wait_is_reported_by_the_next_call(cfg):
+    """step_k_pair_kernel's waits between the waves of a workgroup are bounded; one that ran out sets a word of mapped host
+    memory, and the next r6_step_k call must fail with R6_E_DEVICE instead of returning incomplete outputs silently.  The
+    kernel side is provoked by scripts/stepk_abort_check.py (an 8-poll build); here the word is set through the library's test
+    hook and the host side is checked -- and cleared again, the state is process-wide."""
+    import ctypes as C
+
+    import torch
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, _lib
+
+    env = BatchedRocket6DOF(4096, cfg, integrator="euler", timestep=0.04, seed=5)
+    env.reset()
+    acts = (torch.rand((4, 4096, 3), generator=torch.Generator().manual_seed(3)) * 2 - 1).to(env.device)
+    env.step_k(acts)                          # the pair form (at most one tile per SIMD) creates the word
+    torch.cuda.synchronize()
+    hook = env.lib.r6_internal_test_pair_abort
+    hook.argtypes, hook.restype = [C.c_int], C.c_int
+    assert hook(1) == 1
+    try:
+        with pytest.raises(_lib.R6Error, match="-10003"):
+            env.step_k(acts)
+    finally:
+        assert hook(0) == 1
+    env.step_k(acts)                          # and the library works again
+    torch.cuda.synchronize()
