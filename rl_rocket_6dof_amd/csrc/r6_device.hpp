@@ -240,10 +240,21 @@ __device__ __forceinline__ void rhs13(const float (&y)[kDyn], float im, const Co
 #endif
 
 
+#ifndef R6_VGPR_STEP
+#define R6_VGPR_STEP 1
+#endif
 // One application of the Euler / RK4 map.
 template <int INTEG>
 __device__ __forceinline__ void step_map(const float (&y0)[kDyn], float mass, const Control& c, const Inertia& J,
-                                         float h, float (&y1)[kDyn]) {
+                                         float h_in, float (&y1)[kDyn]) {
+    // The step and the weights derived from it are wave-uniform, and left alone they sit in scalar registers -- but a vector
+    // instruction with a scalar-register source issues in ~1.8 ns per SIMD on gfx950, one whose sources are all vector registers
+    // (or inline constants / literals) in ~1.2 ns (scripts/valu_operand_bench.hip), and the 96 stage FMAs of an RK4 step all
+    // take a weight.  R6_VGPR_STEP (default 1) keeps the step in a vector register, so the weights are vector values too.
+    float h = h_in;
+#if R6_VGPR_STEP
+    asm volatile("" : "+v"(h));
+#endif
     float kend[kDyn];
     if constexpr (INTEG == R6_EULER) {
         rhs13(y0, frcp(mass), c, J, kend);
