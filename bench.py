@@ -258,9 +258,9 @@ SIMDS, ENGINE_CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; peak engine clock 
 
 
 def valu_from_profile(variant: str, integrator: str, n: int, k: int, kernel_ms: float):
-    """The kernel's OTHER limiter next to HBM: share of the launch in which a SIMD issues a VALU instruction, from the
+    """The kernel's OTHER resource next to HBM: VALU instructions per launch x 4 cycles as a share of the launch, from the
     committed PMC pass of THIS workload (SQ_ACTIVE_INST_VALU, quad-cycles per launch; scripts/pmc.sh) and this run's kernel
-    time.  A file constant like `traffic`; the clock is taken at its 2.4 GHz peak, so the share is a lower bound."""
+    time.  A file constant like `traffic`; see the note in the object for what the figure is and is not."""
     path = os.path.join(ROOT, VALU_PROFILE)
     if not (os.path.exists(path) and variant == "raw" and integrator == "rk4" and n == (1 << 20) and k == 1 and kernel_ms > 0):
         return None
@@ -272,10 +272,12 @@ def valu_from_profile(variant: str, integrator: str, n: int, k: int, kernel_ms: 
                 "source": f"{VALU_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); engine clock "
                           f"assumed at its {ENGINE_CLOCK_HZ / 1e9:.1f} GHz peak",
                 "busy_frac_at_2.1GHz": 4.0 * active / SIMDS / (2.1e9 * kernel_ms * 1e-3),
-                "note": "the step kernel is VALU-issue bound at the clock the chip actually holds under it: a clock probe (s_memtime / "
-                        "s_memrealtime per workgroup, profiles/r3_experiments.json) reads 2.03-2.21 GHz during the RK4 step against 2.33-2.37 "
-                        "GHz during the Euler step, so the issue share is 0.70-0.76 of a launch whose first ~4 us (every wave waiting for "
-                        "its first tile) cannot issue anything; HBM is busy for about two thirds of the launch"}
+                "note": "SQ_ACTIVE_INST_VALU counts one quad-cycle per VALU instruction, so busy_frac is the share of the launch at "
+                        "FOUR cycles per instruction -- an upper bound of the pipe's occupancy: a microbenchmark (scripts/valu_operand_bench.hip, "
+                        "profiles/r3_experiments.json) issues a wave64 VALU instruction with vector / constant sources every 1.2 ns per SIMD once "
+                        "two waves are ready (1.8 ns with a scalar-register source, 3.4 ns transcendental), which makes this kernel's VALU work "
+                        "about 21 us next to a 30.6 us memory skeleton: the launch is bounded by how the two overlap (3 of 5 waves per SIMD "
+                        "alive on average), not by either alone; shader clock under the kernel 2.03-2.21 GHz (clock probe)"}
     except Exception:
         return None
 
