@@ -26,7 +26,12 @@ traffic["ratio_to_algorithmic"] = traffic["hbm_bytes_per_launch"] / traffic["alg
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 if os.path.isdir(pmc):
     res = collections.OrderedDict()
-    for f in sorted(glob.glob(os.path.join(pmc, "g*", "**", "*counter_collection.csv"), recursive=True)):
+    newest = {}      # gpurun_out/ keeps the files of earlier passes next to the latest: one (the newest) per counter group
+    for f in glob.glob(os.path.join(pmc, "g*", "**", "*counter_collection.csv"), recursive=True):
+        g = os.path.relpath(f, pmc).split(os.sep)[0]
+        if g not in newest or os.path.getmtime(f) > os.path.getmtime(newest[g]):
+            newest[g] = f
+    for f in (newest[g] for g in sorted(newest)):
         by = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "step_kernel" in r["Kernel_Name"]:
