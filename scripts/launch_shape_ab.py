@@ -17,6 +17,7 @@ ap.add_argument("--integrator", default="rk4")
 ap.add_argument("--wrapped", action="store_true")
 ap.add_argument("--shapes", default="base;tail=0.03125;tail=0.0625;tail=0.09375;tail=0.125;split=0.5;split=0.45;split=0.55;split=0.5,tail=0.0625")
 ap.add_argument("--nocheck", action="store_true")
+ap.add_argument("--alternate", action="store_true", help="every other round walks the builds / shapes in reverse order (the first one of a round reads slow)")
 ap.add_argument("--graph", type=int, default=0, help="> 0: time replays of a HIP graph of this many captured steps instead of eager launches")
 args = ap.parse_args()
 cfg = default_env_config()
@@ -102,7 +103,7 @@ if args.graph > 0:
         graphs[(l, sh)] = g
     torch.cuda.synchronize()
 for r in range(args.rounds):
-    for (l, sh) in names:
+    for (l, sh) in (names[::-1] if (args.alternate and r % 2) else names):
         e = envs[l]
         apply(sh, e.lib)
         for j in range(10):
