@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     // pulling them from an LDS counter inside a workgroup helps the Euler instances only (see below).
     const int64_t n_full = n >> 6;  // tiles [0, n_full) are full; tile n_full (if any) is partial
     int tile_no = 0;
-    constexpr bool kPrefetch = (INTEG == R6_EULER);
+    constexpr bool kPrefetch = (INTEG == R6_EULER) || (R6_PREFETCH_ALL != 0);   // R6_PREFETCH_ALL: A/B (with R6_EARLY_LOAD=0): the RK4 instances prefetch into registers too
     TileIn nxt;
     bool have_nxt = false;
     // Tile hand-out inside a workgroup (Euler instances).  The four waves of a workgroup sit on the four SIMDs of a
@@ -1082,6 +1082,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
 // Every wait is bounded: a wave that does not see its partner's counter move for ~0.1 s raises the workgroup's abort word and
 // both leave (outputs then incomplete -- a partner that never arrives means the launch was broken anyway); the grid always drains.
 // -------------------------------------------------------------------------------------------------
+#ifndef R6_PREFETCH_ALL
+#define R6_PREFETCH_ALL 0
+#endif
 #ifndef R6_PAIR_SPIN_LOG2
 #define R6_PAIR_SPIN_LOG2 21   // polls of a bounded wait (about 0.1 s); a dev build with 3 provokes the abort path (scripts/stepk_abort_check.py)
 #endif
