@@ -225,6 +225,9 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
     }
 }
 
+#ifndef R6_PREFETCH_ALL
+#define R6_PREFETCH_ALL 0   // A/B: 1 (with -DR6_EARLY_LOAD=0) makes the RK4 instances prefetch the next tile into registers like the Euler ones
+#endif
 #ifndef R6_RK4_WAVES
 #define R6_RK4_WAVES 5
 #endif
@@ -1082,9 +1085,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : 4)) void step_k_ker
 // Every wait is bounded: a wave that does not see its partner's counter move for ~0.1 s raises the workgroup's abort word and
 // both leave (outputs then incomplete -- a partner that never arrives means the launch was broken anyway); the grid always drains.
 // -------------------------------------------------------------------------------------------------
-#ifndef R6_PREFETCH_ALL
-#define R6_PREFETCH_ALL 0
-#endif
 #ifndef R6_PAIR_SPIN_LOG2
 #define R6_PAIR_SPIN_LOG2 21   // polls of a bounded wait (about 0.1 s); a dev build with 3 provokes the abort path (scripts/stepk_abort_check.py)
 #endif
