@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the batched Rocket6DOF.step() hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 from a plain shell: starts its own N ranks (launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -491,10 +491,104 @@ def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) 
             "episodes_seen": float(sum(float(t[:, 0].sum()) for t in gathers[n_before:]))}
 
 
+RANK_SCRIPT = os.path.abspath(__file__)     # what every rank of a self-launched job runs (tests point it at a GPU-free stand-in)
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int, argv, script: str = None) -> int:
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): this process becomes the LAUNCHER.  It
+    never imports torch.cuda nor touches a GPU; it starts
+
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>
+
+    as a CHILD process (no os.exec*: a GPU box refuses an exec from a process that has initialised the GPU, and the launcher
+    has to outlive the job to report on it), relays the child's stdout -- rank 0's ONE JSON line -- and returns the child's
+    return code.  Loud when it cannot: a child that fails, or that ends without a line whose n_gpus == N, makes the launcher
+    exit non-zero with the reason on stderr.  The reference has no launcher to mirror (main_6DOF.py:155-156 is one process,
+    n_envs = 1); the job it replaces is the loop of main_6DOF.py:105-139."""
+    script = script or RANK_SCRIPT
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["R6_BENCH_LAUNCHER_PID"] = str(os.getpid())
+    print(f"[bench] launcher: {n_ranks} ranks, one per GPU: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)   # own process group
+    seen = None
+    try:
+        for ln in proc.stdout:       # rank 0's line (and whatever else a rank prints to stdout) goes through as it comes
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            if ln.lstrip().startswith("{"):
+                try:
+                    rec = json.loads(ln)
+                    if isinstance(rec, dict) and "n_gpus" in rec:
+                        seen = rec
+                except ValueError:
+                    pass
+        rc = proc.wait()
+    except BaseException:
+        if proc.poll() is None:      # interrupted: end the exact process group this launcher started (torchrun and its ranks)
+            import signal
+
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+                proc.wait(timeout=20)
+            except (OSError, subprocess.TimeoutExpired):
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+        raise
+    if rc != 0:
+        print(f"[bench] launcher: the {n_ranks}-rank job FAILED (torch.distributed.run returned {rc}); no scaling record", file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    if seen is None or seen.get("n_gpus") != n_ranks:
+        got = "no JSON line" if seen is None else f"a line with n_gpus = {seen.get('n_gpus')}"
+        print(f"[bench] launcher: asked for {n_ranks} ranks but the job printed {got}", file=sys.stderr)
+        return 3
+    return 0
+
+
+def check_world(args) -> "int | None":
+    """How many ranks the environment says there are against --gpus.  None: not launched yet (no WORLD_SIZE) and --gpus > 1 --
+    this process must become the launcher.  A WORLD_SIZE that disagrees with --gpus ends the run, whatever the two numbers
+    (round 3 raised only for WORLD_SIZE > 1: `--gpus 8` from a plain shell stepped one GPU and printed n_gpus 1)."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is None:
+        return None if args.gpus > 1 else 1
+    try:
+        world = int(ws)
+    except ValueError:
+        raise SystemExit(f"bench.py: WORLD_SIZE={ws!r} is not a number")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` from a plain "
+                         f"shell (it launches its own ranks) or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    return world
+
+
 def main(argv=None):
     args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if args.k > 1 and args.steps % args.k:
         raise SystemExit("--steps must be a multiple of --k")
+    if check_world(args) is None:
+        # BEFORE anything imports torch.cuda: the launcher process never owns a GPU context
+        rc = launch_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv))
+        if rc != 0:
+            raise SystemExit(rc)
+        return
 
     import torch
     import torch.distributed as dist
@@ -515,7 +609,7 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(int(os.environ.get("R6_FORCE_DEVICE", local)))
         dist.init_process_group(backend=os.environ.get("R6_DIST_BACKEND") or "nccl", rank=0, world_size=1)
-    if world != args.gpus and world > 1:
+    if world != args.gpus:     # check_world() above saw the same WORLD_SIZE: cannot happen, and must not pass silently if it does
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product has no CPU path)")

@@ -53,18 +53,30 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+_AGREE_GENERATION: Dict[str, int] = {}     # calls made so far per key: the ranks call in the same order, so their counters agree
+
+
 def all_ranks_agree(ok: bool, key: str) -> bool:
     """True iff EVERY rank passed ok=True.  Goes through the default process group's key-value store (the TCP rendezvous
     store), not through a collective of any backend -- usable to decide which backend's collectives to use next.  Without a
-    process group: ``ok``."""
+    process group (or without access to its store): ``ok``.
+
+    Every call writes keys of its own generation (``r6/<key>/<call number>/<rank>``): a second call with the same key never
+    reads the answers of the first (``get`` on an existing key does not block, so stale entries would let ranks decide
+    differently -- the split-backend hang this function exists to prevent)."""
     if not (dist.is_available() and dist.is_initialized()):
         return bool(ok)
-    from torch.distributed import distributed_c10d as c10d
+    try:
+        from torch.distributed import distributed_c10d as c10d
 
-    store = c10d._get_default_store()
+        store = c10d._get_default_store()       # private API: guarded
+    except Exception:
+        return bool(ok)
     rank, world = dist.get_rank(), dist.get_world_size()
-    store.set(f"r6/{key}/{rank}", "1" if ok else "0")
-    return all(store.get(f"r6/{key}/{r}") == b"1" for r in range(world))     # get() blocks until the key exists
+    gen = _AGREE_GENERATION.get(key, 0)
+    _AGREE_GENERATION[key] = gen + 1
+    store.set(f"r6/{key}/{gen}/{rank}", "1" if ok else "0")
+    return all(store.get(f"r6/{key}/{gen}/{r}") == b"1" for r in range(world))     # get() blocks until the key exists
 
 
 def gather_episode_stats(local: Dict[str, float], device=None) -> Tuple[Dict[str, float], torch.Tensor]:

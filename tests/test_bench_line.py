@@ -50,6 +50,71 @@ def test_k_must_divide_steps():
         bench.main(["--k", "16", "--steps", "100"])
 
 
+STUB = os.path.join(ROOT, "tests", "_bench_rank_stub.py")
+
+
+def _no_dist_env(monkeypatch):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_gpus_n_from_a_plain_shell_launches_n_ranks(monkeypatch, capfd):
+    """Round-3 review, item 1: `python bench.py --gpus 2` with no WORLD_SIZE must become a 2-rank job by itself (a child
+    torch.distributed.run), relay rank 0's line and exit 0 -- not step one GPU and print n_gpus 1.  The ranks here are
+    GPU-free stand-ins over gloo (tests/_bench_rank_stub.py); the launcher, the argument relay and the checks are bench.py's."""
+    _no_dist_env(monkeypatch)
+    monkeypatch.setattr(bench, "RANK_SCRIPT", STUB)
+    bench.main(["--gpus", "2", "--steps", "2000", "--warmup", "100"])
+    out, err = capfd.readouterr()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl"]["rccl_ranks"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["steps"] == 2000 and line["warmup"] == 100                      # the same arguments reached the ranks
+    assert line["value"] == pytest.approx(2 * (1 << 20) * 2000 / 0.084)        # whole job over the slowest rank
+    assert line["rccl"]["with_rollout_gather"]["episodes_seen"] == 3.0
+    assert "torch.distributed.run" in err and "--nproc-per-node=2" in err
+
+
+def test_launcher_is_loud_when_a_rank_fails_or_the_world_is_wrong(monkeypatch, capfd):
+    _no_dist_env(monkeypatch)
+    monkeypatch.setattr(bench, "RANK_SCRIPT", STUB)
+    monkeypatch.setenv("R6_STUB_FAIL_RANK", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"])
+    assert e.value.code not in (0, None)
+    assert "FAILED" in capfd.readouterr().err
+    monkeypatch.delenv("R6_STUB_FAIL_RANK")
+    monkeypatch.setenv("R6_STUB_WRONG_WORLD", "1")       # a job that ends well but reports the wrong number of ranks
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"])
+    assert e.value.code == 3 and "n_gpus = 1" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("world,gpus", [("1", "8"), ("2", "1"), ("4", "8"), ("x", "1")])
+def test_world_size_that_disagrees_with_gpus_ends_the_run(monkeypatch, world, gpus):
+    """... in every case, world == 1 included (round 3: `WORLD_SIZE=1 bench.py --gpus 8` ran one rank and said n_gpus 1)."""
+    monkeypatch.setenv("WORLD_SIZE", world)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", gpus])
+    assert e.value.code not in (0, None)
+
+
+def test_launcher_process_never_loads_the_gpu_runtime():
+    """The launcher must not own a GPU context (the ranks are its children): a fresh interpreter that takes the launcher branch
+    has not imported torch when launch_ranks() is reached."""
+    import subprocess
+
+    code = ("import sys, os; sys.path.insert(0, %r); os.environ.pop('WORLD_SIZE', None); import bench\n"
+            "def fake(n, argv, script=None):\n"
+            "    assert 'torch' not in sys.modules, 'launcher imported torch'\n"
+            "    print('LAUNCH', n, argv); return 0\n"
+            "bench.launch_ranks = fake; bench.main(['--gpus', '8', '--steps', '5'])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "LAUNCH 8 ['--gpus', '8', '--steps', '5']" in r.stdout
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -71,6 +136,9 @@ def _worker(rank, world, port, q):
     # the gloo-or-RCCL decision of bench.py is a GROUP decision: one rank without a gloo group switches every rank
     assert r6dist.all_ranks_agree(True, "t1") is True
     assert r6dist.all_ranks_agree(rank != 1, "t2") is False
+    # the same key again with other answers: every call is its own generation, nothing of the first call is read back
+    assert r6dist.all_ranks_agree(True, "t2") is True
+    assert r6dist.all_ranks_agree(rank != 0, "t1") is False
     tot, _ = r6dist.gather_episode_stats({k: float(rank + 1) for k in r6dist.STAT_NAMES})
     args = b.parse_args(["--gpus", "2", "--steps", "2000", "--warmup", "100"])
     extras = {"rccl": {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
