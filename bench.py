@@ -525,16 +525,20 @@ def launch_ranks(n_ranks: int, argv, script: str = None) -> int:
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)   # own process group
     seen = None
     try:
-        for ln in proc.stdout:       # rank 0's line (and whatever else a rank prints to stdout) goes through as it comes
-            sys.stdout.write(ln)
-            sys.stdout.flush()
+        for ln in proc.stdout:       # rank 0's line goes to stdout as it comes; anything else a rank or a library prints there
+            rec = None               # ("[Gloo] Rank 0 is connected ...") goes to stderr: the launcher's stdout is the ONE line
             if ln.lstrip().startswith("{"):
                 try:
                     rec = json.loads(ln)
-                    if isinstance(rec, dict) and "n_gpus" in rec:
-                        seen = rec
                 except ValueError:
-                    pass
+                    rec = None
+            if isinstance(rec, dict) and "n_gpus" in rec:
+                seen = rec
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(ln)
+                sys.stderr.flush()
         rc = proc.wait()
     except BaseException:
         if proc.poll() is None:      # interrupted: end the exact process group this launcher started (torchrun and its ranks)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define R6_ABI_VERSION 6
+#define R6_ABI_VERSION 7
 #define R6_STATE_DIM 14
 #define R6_ACTION_DIM 3
 #define R6_NUM_TERMS 8 /* atarg|vtarg_tracking, thrust_penalty, eta, attitude_constraint,
@@ -47,7 +47,7 @@ enum { R6_SHAPING_ACCELERATION = 0, R6_SHAPING_VELOCITY = 1 };
 enum { R6_REWARD_STANDARD = 0, R6_REWARD_ANNEALED = 1 };
 /* bits of R6Buffers.flags[i] */
 enum { R6_FLAG_GROUND = 1, R6_FLAG_BOUNDS = 2, R6_FLAG_TRUNCATED = 4 };
-enum { R6_E_BADARG = -10001, R6_E_ALIGN = -10002, R6_E_DEVICE = -10003 /* a kernel of an earlier call reported a failed launch-internal wait: see r6_step_k */ };
+enum { R6_E_BADARG = -10001, R6_E_ALIGN = -10002, R6_E_DEVICE = -10003 /* a kernel of an earlier call reported a failed launch-internal wait: see r6_device_status */ };
 /* columns of R6Buffers.stats */
 #define R6_NUM_STATS 8
 enum {
@@ -149,14 +149,21 @@ typedef struct R6Buffers {
 int r6_abi_version(void);
 size_t r6_params_size(void);   /* sizeof(R6Params), for binding self-checks */
 size_t r6_buffers_size(void);  /* sizeof(R6Buffers) */
-const char *r6_last_error(void);
+const char *r6_last_error(void);  /* text of the last failure on this thread; a raised device error word (below) outranks it */
 
-/* Launch-shape knobs of r6_step (process-wide; results never depend on them, only which wave computes which tile and how
- * many launches carry a step).  Keys: "even_xcd_share" (share of the tiles given to the workgroups on even XCDs, < 0 = default),
- * "tail_frac" (share of the tiles left to late-dispatched tail workgroups, 0 = none), "tail_tiles_per_wave",
- * "split" (1: large shards run as two launches fork/joined on a library-owned stream), "split_frac", "split_min_tiles",
- * "grid_blocks" (> 0 pins the persistent grid), "sweep" (tile order on odd steps, -1 = default).  The same knobs are read once
- * from the environment: R6_EVEN_XCD_SHARE, R6_TAIL_FRAC, R6_TAIL_TPW, R6_SPLIT, R6_SPLIT_FRAC, R6_GRID_BLOCKS, R6_SWEEP. */
+/* Device-side error word (process-wide, sticky).  A kernel whose launch-internal bounded wait ran out (r6_step_k's waves that hand
+ * each other work through LDS) sets a word of mapped host memory before it exits; from then on r6_step, r6_step_k and r6_rollout
+ * return R6_E_DEVICE without launching (the envs that kernel stepped are in an unknown state) and r6_last_error() says why --
+ * whichever call comes next, not only r6_step_k.  r6_device_status(): 0, or R6_E_DEVICE while the word is raised (also after the
+ * LAST launch of a run, once the stream has been synchronised).  r6_clear_device_error(): the caller has re-initialised its envs
+ * (r6_reset); clears the word and returns the status it had. */
+int r6_device_status(void);
+int r6_clear_device_error(void);
+
+/* Launch-shape knobs of r6_step (process-wide; results never depend on them, only which wave computes which tile).  Keys:
+ * "even_xcd_share" (share of the tiles given to the workgroups on even XCDs, < 0 = default), "grid_blocks" (> 0 pins the
+ * persistent grid), "sweep" (tile order on odd steps, -1 = default), "sweep_flags" (4: no wave-priority ladder).  The first three
+ * are also read once from the environment: R6_EVEN_XCD_SHARE, R6_GRID_BLOCKS, R6_SWEEP. */
 int r6_tune(const char *key, double value);
 
 /* Rocket6DOF.step for n envs (rocket_env.py:201-231): denormalise action, integrate one env
@@ -178,8 +185,10 @@ int r6_step(const R6Params *params, const R6Buffers *buf, uint64_t seed, uint64_
  *   final_obs (k,n,obs_dim), fin_return / fin_length (k,n) out.
  * state, epconst, ep_step, ep_return, stats are the same single arrays as in r6_step (read before / written after).
  * Batches of at most one 64-env tile per SIMD run as two kinds of waves per tile (dynamics / reward) that hand each other
- * work through LDS; their waits are bounded, and a wait that ever ran out is reported by the NEXT r6_step_k call of the
- * process as R6_E_DEVICE (sticky: the stepped envs are in an unknown state) -- never silently. */
+ * work through LDS; their waits are bounded, and a wait that ever ran out raises the device error word (r6_device_status above):
+ * every later stepping call of the process fails with R6_E_DEVICE until r6_clear_device_error() -- never silently.  (That form is
+ * not used when k > 1 steps write ONE reward / terms buffer -- stride 0 without R6_K_LAST_ONLY -- where only the in-order kernel
+ * leaves the last step's values.) */
 enum { R6_K_LAST_ONLY = 1 /* only the last step's per-step outputs are stored (throughput rollouts, burn-in) */ };
 typedef struct R6StepK {
     int32_t k;                /* env steps in this launch, 1..65536 */
@@ -267,7 +276,9 @@ int r6_policy_act(const R6PolicyNet *net, const float *obs, int64_t n, float *ac
  * R6Buffers supplies state / epconst / ep_step / ep_return / stats / step_base (in/out as in r6_step) and, optionally, final_obs /
  * fin_return / fin_length (rows of finished envs, overwritten step after step as K r6_step calls would) and obs (the observation
  * after the LAST step, = obs_seq row k); its action / reward / done / flags members are not used.
- * Supported: R6PolicyNet hidden (64,64) | (128,64), obs_dim 13 | 14 equal to R6Params.obs_dim; euler / rk4 with n_substeps 1. */
+ * final_obs / fin_return / fin_length are written under R6Params.auto_reset only, as in r6_step.
+ * Supported: R6PolicyNet hidden (64,64) | (128,64), obs_dim 13 | 14 equal to R6Params.obs_dim; n_substeps 1; rk4 with either
+ * reward shaping, euler with acceleration shaping (euler + velocity shaping has no instance: R6_E_BADARG). */
 typedef struct R6Rollout {
     int32_t k;              /* env steps in this launch, 1..65536 */
     int32_t deterministic;  /* 0: sampled actions (training rollouts); 1: the mean action (evaluation, montecarlo_script.py) */

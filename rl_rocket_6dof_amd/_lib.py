@@ -9,13 +9,13 @@ import os
 
 from .params import R6Buffers, R6Params, R6PolicyGrad, R6PolicyNet, R6Rollout, R6StepK
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _LIBS = {}
 
 SYMBOLS = ("r6_abi_version", "r6_params_size", "r6_buffers_size", "r6_last_error", "r6_step", "r6_step_k", "r6_stepk_size", "r6_reset",
            "r6_observe", "r6_sim_step", "r6_rhs", "r6_policy_net_size", "r6_policy_act", "r6_ppo_loss_grad",
            "r6_policy_grad_size", "r6_ppo_scratch_floats", "r6_ppo_minibatch_grad", "r6_minibatch_adv_norm", "r6_adam_clip_step",
-           "r6_gae", "r6_permutation", "r6_tune", "r6_rollout", "r6_rollout_size")
+           "r6_gae", "r6_permutation", "r6_tune", "r6_rollout", "r6_rollout_size", "r6_device_status", "r6_clear_device_error")
 
 
 class R6Error(RuntimeError):
@@ -76,6 +76,8 @@ def load(path: str | None = None):
     lib.r6_rollout.argtypes = [C.POINTER(R6Params), C.POINTER(R6Buffers), C.POINTER(R6PolicyNet), C.POINTER(R6Rollout), u64, u64, u64, u64,
                                vp, u64, vp]
     lib.r6_rollout.restype = C.c_int
+    lib.r6_device_status.restype = C.c_int
+    lib.r6_clear_device_error.restype = C.c_int
     if lib.r6_rollout_size() != C.sizeof(R6Rollout):
         raise ImportError("R6Rollout layout mismatch between params.py and libr6dof.so: rebuild")
     if lib.r6_policy_grad_size() != C.sizeof(R6PolicyGrad):
@@ -106,3 +108,13 @@ def tune(key: str, value: float, lib=None):
     """Sets a launch-shape knob of ``r6_step`` (include/r6dof.h ``r6_tune``); results never depend on it."""
     lib = lib if lib is not None else load()
     check(lib.r6_tune(key.encode(), float(value)), "r6_tune", lib)
+
+
+def device_status(lib=None) -> int:
+    """0, or R6_E_DEVICE while the library's device error word is raised (include/r6dof.h ``r6_device_status``)."""
+    return int((lib if lib is not None else load()).r6_device_status())
+
+
+def clear_device_error(lib=None) -> int:
+    """Clears the device error word (after the caller has re-initialised its envs); returns the status it had."""
+    return int((lib if lib is not None else load()).r6_clear_device_error())

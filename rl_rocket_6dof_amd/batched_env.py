@@ -394,6 +394,11 @@ class BatchedRocket6DOF(VecEnv):
         n, od, dev = self.num_envs, self.obs_dim, self.device
         if policy.obs_dim != od or policy.device != dev:
             raise ValueError("policy and env disagree on obs_dim / device")
+        if getattr(policy, "env_offset", self.env_offset) != self.env_offset:
+            # r6_rollout takes ONE env_offset for the reset stream and the action-noise stream; a policy built with another offset
+            # would draw other noise in policy.forward() than in here, silently
+            raise ValueError(f"rollout: policy.env_offset {policy.env_offset} != env.env_offset {self.env_offset}: the fused rollout keys "
+                             "the action noise by the env's global index; build the policy with the env's offset")
 
         def chk(t, name, shape, dtype):
             if t is None:

@@ -38,19 +38,76 @@ def is_stale() -> bool:
     return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not is_stale():
-        return LIB
-    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
-           "-fno-math-errno", "-fno-slp-vectorize",   # packed-f32 (v_pk_*) SLP code is slower here: A/B 52 -> 46 us
-           "-Wall", "-Wno-unused-function", "-Wl,-Bsymbolic",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-fno-math-errno",
+         "-fno-slp-vectorize",   # packed-f32 (v_pk_*) SLP code is slower here: A/B 52 -> 46 us
+         "-Wall", "-Wno-unused-function"]
+OBJ_DIR = os.path.join(CSRC, "build")
+
+
+def _compile_objects(defines, tag: str, force: bool, verbose: bool):
+    """Every source to its own object file, in parallel (one hipcc per translation unit; an unchanged unit is not rebuilt).
+    Objects of a build flavour live under csrc/build/<tag>/ (git-ignored)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    odir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(odir, exist_ok=True)
+    newest_header = max([os.path.getmtime(h) for h in _headers()] + [os.path.getmtime(os.path.abspath(__file__))])
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp, op = os.path.join(CSRC, src), os.path.join(odir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), newest_header):
+            jobs.append([_hipcc(), *FLAGS, *defines, "-c", sp, "-o", op])
+
+    def run(cmd):
+        if verbose:
+            print("[rl_rocket_6dof_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, jobs))
+    return objs
+
+
+def _link(objs, out: str, verbose: bool):
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,-Bsymbolic", *objs, "-o", out + ".tmp"]
     if verbose:
         print("[rl_rocket_6dof_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(out + ".tmp", out)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIB
+    _link(_compile_objects([], "release", force, verbose), LIB, verbose)
     _stamp_commit()
     return LIB
+
+
+TEST_HOOKS_LIB = os.path.join(CSRC, "variants", "libr6dof_testhooks.so")
+
+
+def build_test_hooks(force: bool = False, verbose: bool = True) -> str:
+    """The same sources with -DR6_TEST_HOOKS: exports r6_internal_test_pair_abort (tests/test_gpu_step_k.py raises the device
+    error word with it, as a kernel would).  The release library does not export it."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
+    if not force and os.path.exists(TEST_HOOKS_LIB) and all(os.path.getmtime(f) <= os.path.getmtime(TEST_HOOKS_LIB) for f in srcs):
+        return TEST_HOOKS_LIB
+    os.makedirs(os.path.dirname(TEST_HOOKS_LIB), exist_ok=True)
+    # only the unit that owns the word differs; the other units' objects are the release ones
+    objs = _compile_objects([], "release", False, verbose)
+    hook_dir = os.path.join(OBJ_DIR, "testhooks")
+    os.makedirs(hook_dir, exist_ok=True)
+    hook_obj = os.path.join(hook_dir, "r6_kernels.o")
+    cmd = [_hipcc(), *FLAGS, "-DR6_TEST_HOOKS", "-c", os.path.join(CSRC, "r6_kernels.hip"), "-o", hook_obj]
+    if verbose:
+        print("[rl_rocket_6dof_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    objs = [hook_obj if os.path.basename(o) == "r6_kernels.o" else o for o in objs]
+    _link(objs, TEST_HOOKS_LIB, verbose)
+    return TEST_HOOKS_LIB
 
 
 COMMIT_FILE = os.path.join(CSRC, "BUILD_COMMIT")
@@ -74,3 +131,5 @@ def _stamp_commit():
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    if "--test-hooks" in sys.argv:
+        print(build_test_hooks(force="--force" in sys.argv))

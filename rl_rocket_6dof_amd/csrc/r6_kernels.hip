@@ -240,8 +240,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset,
-                                                      const uint32_t even_share_q16, const uint32_t sweep,
-                                                      const uint32_t main_blocks, const uint32_t tail_tiles) {
+                                                      const uint32_t even_share_q16, const uint32_t sweep) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
     // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
@@ -266,28 +265,17 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
     // equal shares the even XCDs are done at 0.8 of the launch.  even_share_q16 > 0 (persistent grids only): the tile
     // range is cut into an even-XCD pool of n_tiles * share / 65536 tiles and an odd-XCD pool with the rest, each
     // walked round-robin by the waves of its own workgroups.  0: one pool for everybody.
-    //
-    // Tail pool (round 3).  tail_tiles > 0: the launch has more workgroups than the chip holds.  The first `main_blocks`
-    // (= the resident capacity) walk the first n_tiles - tail_tiles tiles as above; the workgroups behind them are
-    // dispatched by the hardware as resident ones exit -- on whichever CU is done first -- and take the last `tail_tiles`
-    // tiles, one tile list entry per wave and round.  The static lists cannot know which SIMD will be late in a given
-    // launch (no correlation between launches); the dispatcher does, and a late workgroup's load latency hides behind the
-    // four workgroups still computing on its CU.
-    const int64_t n_main = n_tiles - (int64_t)tail_tiles;
-    int64_t nw = (int64_t)main_blocks * kWaves;
+    // (Round 3 also measured a pool of late-dispatched tail workgroups, a fork/join split of the shard over two streams and
+    // staggered first loads: +-0, +17 us eager and +-0 -- profiles/r3_experiments.json; removed in round 4.)
+    int64_t nw = (int64_t)gridDim.x * kWaves;
     int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
-    int64_t pool_base = 0, pool_tiles = n_main;
-    if (blockIdx.x >= main_blocks) {
-        pool_base = n_main;
-        pool_tiles = tail_tiles;
-        nw = (int64_t)(gridDim.x - main_blocks) * kWaves;
-        t_first = (int64_t)(blockIdx.x - main_blocks) * kWaves + wave;
-    } else if (even_share_q16 != 0u) {
-        const int64_t n_even = (n_main * (int64_t)even_share_q16) >> 16;
+    int64_t pool_base = 0, pool_tiles = n_tiles;
+    if (even_share_q16 != 0u) {
+        const int64_t n_even = (n_tiles * (int64_t)even_share_q16) >> 16;
         const bool odd = (blockIdx.x & 1u) != 0u;
         pool_base = odd ? n_even : 0;
-        pool_tiles = odd ? n_main - n_even : n_even;
-        nw = (int64_t)(main_blocks >> 1) * kWaves;
+        pool_tiles = odd ? n_tiles - n_even : n_even;
+        nw = (int64_t)(gridDim.x >> 1) * kWaves;
         t_first = (int64_t)(blockIdx.x >> 1) * kWaves + wave;
     }
     const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
@@ -555,12 +543,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? 1 : (INTEG == R6_EULER 
         };
         TileIn cur;
         int64_t t = 0;
-        if (sweep & 8u) {   // A/B: the workgroups that arrive third, fourth, fifth on a CU ask for their first tile later
-            const uint32_t slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;   // HW_ID.wave_id: the wave's slot on its SIMD
-            if (slot >= 2u) __builtin_amdgcn_s_sleep(24);
-            if (slot >= 3u) __builtin_amdgcn_s_sleep(12);
-            if (slot >= 4u) __builtin_amdgcn_s_sleep(12);
-        }
         if (n_pos > 0) {
             t = tile_at(0);
             if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
@@ -1413,8 +1395,8 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     __syncthreads();
     if (b.stats && tid < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] != 0ull)
         b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
-    // an abort leaves this workgroup's outputs incomplete: say so where the host sees it (a word of mapped host memory, read
-    // by the next r6_step_k call and by r6_last_error) -- never silently
+    // an abort leaves this workgroup's outputs incomplete: say so where the host sees it (a word of mapped host memory, read by
+    // r6_device_status(), r6_last_error() and the next r6_step / r6_step_k / r6_rollout call) -- never silently
     if (tid == 0 && host_abort && abort_word != 0) __hip_atomic_store(host_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1565,31 +1547,15 @@ bool device_has_eight_xcds() {
 #ifndef R6_EVEN_SHARE_DEFAULT
 #define R6_EVEN_SHARE_DEFAULT -1.0   // < 0: per-integrator default (RK4 0.54, Euler 0.56)
 #endif
-#ifndef R6_TAIL_FRAC_DEFAULT
-#define R6_TAIL_FRAC_DEFAULT 0.0
-#endif
-#ifndef R6_SPLIT_DEFAULT
-#define R6_SPLIT_DEFAULT 0
-#endif
-
 // ---- launch shape of r6_step: tuning state (defaults from measurements; R6_* environment variables and r6_tune()
 //      override them -- results never depend on any of it, only which wave computes which tile) ----------------------------
 struct StepTune {
     std::atomic<double> even_share{R6_EVEN_SHARE_DEFAULT};   // < 0: per-integrator default
-    std::atomic<double> tail_frac{R6_TAIL_FRAC_DEFAULT};     // share of the tiles in the tail pool (0 = none)
-    std::atomic<int> tail_tpw{1};                            // tiles per wave of a tail workgroup
-    std::atomic<int> split{R6_SPLIT_DEFAULT};                // 0: one launch; 1: two launches fork/joined on a library-owned stream
-    std::atomic<double> split_frac{0.5};                     // share of the envs in the first launch
-    std::atomic<int> split_min_tiles{12288};                 // shards below this many tiles are never split
     std::atomic<int> grid_blocks{0};                         // > 0: pins the persistent grid (R6_GRID_BLOCKS)
     std::atomic<int> sweep{R6_SWEEP_DEFAULT};
-    std::atomic<int> sweep_flags{0};                         // A/B bits passed to the kernel: 4 = no priority ladder, 8 = staggered first loads
+    std::atomic<int> sweep_flags{0};                         // A/B bit passed to the kernel: 4 = no priority ladder
     StepTune() {
         if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) even_share = std::atof(e);
-        if (const char* e = std::getenv("R6_TAIL_FRAC")) tail_frac = std::atof(e);
-        if (const char* e = std::getenv("R6_TAIL_TPW")) tail_tpw = std::atoi(e);
-        if (const char* e = std::getenv("R6_SPLIT")) split = std::atoi(e);
-        if (const char* e = std::getenv("R6_SPLIT_FRAC")) split_frac = std::atof(e);
         if (const char* e = std::getenv("R6_GRID_BLOCKS")) grid_blocks = std::atoi(e);
         if (const char* e = std::getenv("R6_SWEEP")) sweep = std::atoi(e);
     }
@@ -1606,73 +1572,9 @@ uint32_t even_xcd_share_q16(int integrator) {
     return (uint32_t)(f * 65536.0 + 0.5);
 }
 
-// Fork/join resources of one (device, caller stream) pair: a library-owned side stream and two events.  Created on first
-// use outside stream capture (resource creation is not allowed while a stream captures); a caller stream without an entry
-// simply gets the single-launch form.
-struct ForkJoin {
-    int dev = -1;
-    hipStream_t caller = nullptr;
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool used = false;
-};
-ForkJoin* fork_join_for(hipStream_t caller) {
-    static std::mutex mu;
-    static ForkJoin table[32];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto& e : table)
-        if (e.used && e.dev == dev && e.caller == caller) return &e;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    for (auto& e : table) {
-        if (e.used) continue;
-        if (hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        e.dev = dev;
-        e.caller = caller;
-        e.used = true;
-        return &e;
-    }
-    return nullptr;
-}
-
-// The envs [e0, e0 + cnt) of a shard as a shard of their own (e0 a multiple of 64): every pointer advanced, the
-// statistics rows of its workgroups start at `block_base`.  The reset RNG is keyed by the global env index: the caller
-// adds e0 to env_offset.
-R6Buffers sub_shard(const R6Buffers& b, int64_t e0, int64_t cnt, int od, int64_t block_base) {
-    R6Buffers v = b;
-    v.n = cnt;
-    v.state = b.state + e0;
-    v.epconst = b.epconst + e0;
-    v.action = b.action + e0 * R6_ACTION_DIM;
-    v.obs = b.obs + e0 * od;
-    v.reward = b.reward + e0;
-    v.done = b.done + e0;
-    if (b.flags) v.flags = b.flags + e0;
-    if (b.terms) v.terms = b.terms + e0;
-    if (b.final_obs) v.final_obs = b.final_obs + e0 * od;
-    if (b.ep_step) v.ep_step = b.ep_step + e0;
-    if (b.ep_return) v.ep_return = b.ep_return + e0;
-    if (b.fin_return) v.fin_return = b.fin_return + e0;
-    if (b.fin_length) v.fin_length = b.fin_length + e0;
-    if (b.nfev) v.nfev = b.nfev + e0;
-    if (b.stats) v.stats = b.stats + block_base * R6_NUM_STATS;
-    return v;
-}
-
-// One launch of the step kernel over a whole shard; returns the number of workgroups (= statistics rows) it used.
+// One launch of the step kernel over a whole shard.
 template <int INTEG, int SHAPING, int OD>
-int64_t launch_step_one(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s,
-                        int64_t max_blocks, bool allow_tail) {
+void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
     auto kernel = r6::step_kernel<INTEG, SHAPING, OD>;
     if constexpr (INTEG != R6_RK45) {
         // ONE: n_substeps == 1 (the reference's configuration) gets the straight-line integrator instance;
@@ -1687,34 +1589,21 @@ int64_t launch_step_one(const R6Params& p, const R6Buffers& b, uint64_t seed, ui
     int64_t cap = resident_blocks(kernel, slot);
     const int pinned_blocks = tune().grid_blocks.load(std::memory_order_relaxed);
     if (pinned_blocks > 0) cap = pinned_blocks;
-    if (cap > max_blocks) cap = max_blocks;
+    if (cap > R6_MAX_BLOCKS) cap = R6_MAX_BLOCKS;
+    bool balanced = false;   // dispatcher-balanced grid (below)
     if (blocks > cap) {
         // Up to ~3 M envs the grid is the resident capacity (persistent waves, ~3-10 tiles each).  Beyond that the
         // hardware dispatcher balances better than a fixed tile list per wave: two tiles per wave, as many
         // workgroups as the per-workgroup statistics rows allow (N = 2^22: 4.6 -> 5.1 TB/s algorithmic, 2^23:
         // 3.8 -> 4.6, 2^24: 3.8 -> 5.1; at 2^20 / 2^21 the resident grid is 4-13 % faster).
         const int64_t big = n_tiles / (2 * r6::kWaves);
-        blocks = (pinned_blocks <= 0 && n_tiles >= 49152 && big > cap) ? (big < max_blocks ? big : max_blocks) : cap;
+        balanced = pinned_blocks <= 0 && n_tiles >= 49152 && big > cap;
+        blocks = balanced ? (big < R6_MAX_BLOCKS ? big : R6_MAX_BLOCKS) : cap;
     }
     const bool persistent = blocks == cap && n_tiles >= 2 * blocks * r6::kWaves;
-    // Tail pool (see step_kernel): only on the persistent grid
-    uint32_t main_blocks = (uint32_t)blocks, tail_tiles = 0;
-    if (allow_tail && persistent && INTEG != R6_RK45) {
-        const double tf = tune().tail_frac.load(std::memory_order_relaxed);
-        const int tpw = tune().tail_tpw.load(std::memory_order_relaxed);
-        if (tf > 0.0 && tf < 0.5 && tpw >= 1) {
-            const int64_t per_block = (int64_t)r6::kWaves * tpw;
-            int64_t tb = (int64_t)((double)n_tiles * tf / (double)per_block + 0.5);
-            if (blocks + tb > max_blocks) tb = max_blocks - blocks;
-            if (tb > 0) {
-                tail_tiles = (uint32_t)(tb * per_block);
-                blocks += tb;
-            }
-        }
-    }
     // XCD-aware split (see step_kernel): only for the persistent grid, where every wave walks several tiles
     uint32_t even_share = 0;
-    if (persistent && (main_blocks % 8) == 0 && device_has_eight_xcds()) even_share = even_xcd_share_q16(INTEG);
+    if (persistent && (blocks % 8) == 0 && device_has_eight_xcds()) even_share = even_xcd_share_q16(INTEG);
     // Order of the tiles on odd steps (see step_kernel).  Measured in one process at N = 2^20 / 2^21 / 2^22 (us per step;
     // as even steps | every wave's list backwards | whole range mirrored): RK4 38.0 | 39.4 | 38.8, 85.2 | 90.8 | 90.1,
     // 154 | 159 | 162 (the last size runs the dispatcher-balanced grid, where only "mirrored" exists: its three numbers are
@@ -1725,46 +1614,16 @@ int64_t launch_step_one(const R6Params& p, const R6Buffers& b, uint64_t seed, ui
     const int sweep_env = tune().sweep.load(std::memory_order_relaxed);
     const int sweep_mode = sweep_env >= 0 ? sweep_env : (INTEG == R6_EULER ? 1 : 0);
     uint32_t sweep = 0;
-    if (step & 1) sweep = (main_blocks > cap || (blocks > cap && tail_tiles == 0) || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
-    sweep |= (uint32_t)tune().sweep_flags.load(std::memory_order_relaxed) & 12u;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep, main_blocks, tail_tiles);
-    return blocks;
+    if (step & 1) sweep = (blocks > cap || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
+    sweep |= (uint32_t)tune().sweep_flags.load(std::memory_order_relaxed) & 4u;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep);
 }
 
-// r6_step for one shard: one launch, or -- large shards, split enabled -- the shard's two halves as two launches, the
-// first on the caller's stream and the second on a library-owned stream forked from and joined back to it with events
-// (capturable into a HIP graph like any fork/join).  Launches of ONE stream serialise: the ~4 us in which a launch only
-// waits for its first loads and the ~5 us in which its SIMDs run dry one after the other cannot overlap with
-// anything.  The two halves are independent (tiles never interact), so the second half's ramp runs under the first
-// half's tail.  Results are bit-identical to the single launch: which launch computes a tile never matters, and the two
-// grids use disjoint statistics rows.
-template <int INTEG, int SHAPING, int OD>
-void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
-    const int64_t n_tiles = (b.n + 63) / 64;
-    const int split = tune().split.load(std::memory_order_relaxed);
-    if (split != 0 && INTEG != R6_RK45 && n_tiles >= tune().split_min_tiles.load(std::memory_order_relaxed) && b.n < R6_NT_MIN_ENVS) {
-        if (ForkJoin* fj = fork_join_for(s)) {
-            double f = tune().split_frac.load(std::memory_order_relaxed);
-            if (!(f > 0.05 && f < 0.95)) f = 0.5;
-            const int64_t t0 = (int64_t)((double)n_tiles * f + 0.5);
-            const int64_t e0 = t0 * 64;
-            const R6Buffers a = sub_shard(b, 0, e0, OD, 0);
-            if (hipEventRecord(fj->fork, s) == hipSuccess && hipStreamWaitEvent(fj->side, fj->fork, 0) == hipSuccess) {
-                const int64_t blocks_a = launch_step_one<INTEG, SHAPING, OD>(p, a, seed, step, off, s, R6_MAX_BLOCKS / 2, true);
-                const R6Buffers c = sub_shard(b, e0, b.n - e0, OD, blocks_a);
-                launch_step_one<INTEG, SHAPING, OD>(p, c, seed, step, off + (uint64_t)e0, fj->side, R6_MAX_BLOCKS - blocks_a, true);
-                (void)hipEventRecord(fj->join, fj->side);
-                (void)hipStreamWaitEvent(s, fj->join, 0);
-                return;
-            }
-            (void)hipGetLastError();
-        }
-    }
-    launch_step_one<INTEG, SHAPING, OD>(p, b, seed, step, off, s, R6_MAX_BLOCKS, true);
-}
-
-// The word step_k_pair_kernel raises when one of its bounded waits ran out: mapped host memory, allocated at the first launch
-// outside a stream capture (an allocation would break the capture; a launch captured before any eager one runs without the word).
+// The device error word: step_k_pair_kernel raises it when one of its bounded waits ran out.  Mapped host memory, allocated by the
+// first stepping entry point (r6_reset / r6_step / r6_step_k / r6_rollout) that runs outside a stream capture (an allocation
+// would break the capture); a pair launch that would have to go without the word -- captured before any eager call -- uses the
+// one-wave-per-tile kernel instead, which has no waits.  Read by r6_device_status(), r6_last_error() and at the top of every
+// entry point that steps envs; cleared only by r6_clear_device_error().
 static std::atomic<int*> g_pair_abort_host{nullptr};
 static std::atomic<int*> g_pair_abort_dev{nullptr};
 static int* pair_abort_word(hipStream_t s) {
@@ -1798,6 +1657,17 @@ static bool pair_abort_raised() {
     int* h = g_pair_abort_host.load(std::memory_order_acquire);
     return h && *reinterpret_cast<volatile int*>(h) != 0;
 }
+static const char kDeviceErrorText[] =
+    "a kernel of an earlier call of this process gave up a bounded wait between the waves of a workgroup (step_k_pair_kernel): "
+    "its outputs are incomplete and the envs it stepped are in an unknown state; re-initialise them (r6_reset) and call "
+    "r6_clear_device_error()";
+// Top of every entry point that steps envs: makes the word exist (eager calls) and refuses to step on after an abort.
+static int device_error_guard(const char* who, hipStream_t s) {
+    (void)pair_abort_word(s);
+    if (!pair_abort_raised()) return 0;
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", who, kDeviceErrorText);
+    return R6_E_DEVICE;
+}
 
 template <int INTEG, int SHAPING, int OD>
 void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk, uint64_t seed, uint64_t step, uint64_t off, hipStream_t s) {
@@ -1805,14 +1675,20 @@ void launch_step_k_inst(const R6Params& p, const R6Buffers& b, const R6StepK& sk
         // at most one 64-env tile per SIMD: the two-waves-per-tile form (step_k_pair_kernel).  R6_K_PAIR=0|1 overrides.
         static const int pair_env = [] { const char* e = std::getenv("R6_K_PAIR"); return e ? std::atoi(e) : -1; }();
         const int64_t n_tiles = (b.n + 63) / 64;
-        const bool pair = p.n_substeps == 1 && (pair_env >= 0 ? pair_env != 0 : n_tiles <= R6_K_DIRECT_MAX_TILES);
+        // Not the pair form when several steps would write ONE reward / terms buffer (stride 0 without R6_K_LAST_ONLY: "all steps
+        // write the same buffer, as K r6_step calls would"): the stores of steps k and k + 1 come from two different reward
+        // waves, unordered against each other, and the buffer could end up holding step K - 2.  The one-wave kernel is in order.
+        const bool same_buffer = sk.k > 1 && !(sk.flags & R6_K_LAST_ONLY) && (sk.reward_stride == 0 || (b.terms && sk.terms_stride == 0));
+        int* const abort_word = pair_abort_word(s);    // nullptr: captured before any eager call -- no pair form without the word
+        const bool pair = p.n_substeps == 1 && !same_buffer && abort_word != nullptr &&
+                          (pair_env >= 0 ? pair_env != 0 : n_tiles <= R6_K_DIRECT_MAX_TILES);
         if (pair) {
             int64_t blocks = (n_tiles + r6::kPairTiles - 1) / r6::kPairTiles;
             if (blocks > R6_MAX_BLOCKS) blocks = R6_MAX_BLOCKS;
             R6StepK skl = sk;
             skl.flags = sk.flags & ~R6_K_DIRECT_OBS_INTERNAL;
             hipLaunchKernelGGL((r6::step_k_pair_kernel<INTEG, SHAPING, OD>), dim3((unsigned)blocks), dim3(r6::kPairBlock), 0, s, p, b, skl, seed, step, off,
-                               pair_abort_word(s));
+                               abort_word);
             return;
         }
     }
@@ -1855,30 +1731,39 @@ extern "C" {
 
 // shared with r6_policy.hip (not part of the public header)
 void r6_internal_set_error(const char* what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
-// test hook (tests/test_gpu_step_k.py; not part of the public header): sets (1) or clears (0) the word step_k_pair_kernel raises
-// when a bounded wait ran out, as a kernel would; returns 0 when the word does not exist yet (no pair launch so far).
+// shared with r6_rollout.hip (not part of the public header): the guard of the stepping entry points
+int r6_internal_device_error_guard(const char* who, void* stream) { return device_error_guard(who, static_cast<hipStream_t>(stream)); }
+#ifdef R6_TEST_HOOKS
+// test hook (tests/test_gpu_step_k.py; libr6dof_testhooks.so only -- the release library does not export it): raises the device
+// error word as a kernel would; returns 0 when the word does not exist yet (no stepping call so far).
 int r6_internal_test_pair_abort(int raise) {
     int* h = g_pair_abort_host.load(std::memory_order_acquire);
     if (!h) return 0;
     *reinterpret_cast<volatile int*>(h) = raise ? 1 : 0;
     return 1;
 }
+#endif
 size_t r6_policy_net_size(void) { return sizeof(R6PolicyNet); }
 
 int r6_abi_version(void) { return R6_ABI_VERSION; }
 size_t r6_params_size(void) { return sizeof(R6Params); }
 size_t r6_buffers_size(void) { return sizeof(R6Buffers); }
-const char* r6_last_error(void) { return g_err; }
+const char* r6_last_error(void) {
+    // a raised device error word outranks whatever the last call of this thread said: it is never reported late or not at all
+    if (pair_abort_raised() && !std::strstr(g_err, "bounded wait")) std::snprintf(g_err, sizeof(g_err), "device error: %s", kDeviceErrorText);
+    return g_err;
+}
+int r6_device_status(void) { return pair_abort_raised() ? R6_E_DEVICE : 0; }
+int r6_clear_device_error(void) {
+    const int was = r6_device_status();
+    if (int* h = g_pair_abort_host.load(std::memory_order_acquire)) *reinterpret_cast<volatile int*>(h) = 0;
+    return was;
+}
 
 int r6_tune(const char* key, double value) {
     if (!key) return fail(R6_E_BADARG, "r6_tune: null key");
     StepTune& t = tune();
     if (!std::strcmp(key, "even_xcd_share")) t.even_share = value;
-    else if (!std::strcmp(key, "tail_frac")) t.tail_frac = value;
-    else if (!std::strcmp(key, "tail_tiles_per_wave")) t.tail_tpw = (int)value;
-    else if (!std::strcmp(key, "split")) t.split = (int)value;
-    else if (!std::strcmp(key, "split_frac")) t.split_frac = value;
-    else if (!std::strcmp(key, "split_min_tiles")) t.split_min_tiles = (int)value;
     else if (!std::strcmp(key, "grid_blocks")) t.grid_blocks = (int)value;
     else if (!std::strcmp(key, "sweep")) t.sweep = (int)value;
     else if (!std::strcmp(key, "sweep_flags")) t.sweep_flags = (int)value;
@@ -1896,6 +1781,7 @@ int r6_step(const R6Params* params, const R6Buffers* buf, uint64_t seed, uint64_
     if (!aligned16(b.action) || !aligned16(b.obs))
         return fail(R6_E_ALIGN, "r6_step: action and obs must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = device_error_guard("r6_step", s)) return rc;
     const R6Params& p = *params;
     if (p.integrator == R6_RK45) {
         if (p.shaping == R6_SHAPING_ACCELERATION)
@@ -1922,9 +1808,7 @@ int r6_step_k(const R6Params* params, const R6Buffers* buf, const R6StepK* steps
               uint64_t env_offset, void* stream) {
     if (int rc = validate_common(params, buf)) return rc;
     if (!steps) return fail(R6_E_BADARG, "r6_step_k: null R6StepK");
-    if (pair_abort_raised())
-        return fail(R6_E_DEVICE, "r6_step_k: an earlier launch of this process gave up a bounded wait between the waves of a workgroup "
-                                 "(step_k_pair_kernel): its outputs are incomplete and the envs it stepped are in an unknown state");
+    if (int rc = device_error_guard("r6_step_k", static_cast<hipStream_t>(stream))) return rc;
     const R6Buffers& b = *buf;
     const R6StepK& sk = *steps;
     if (sk.k < 1 || sk.k > 65536) return fail(R6_E_BADARG, "r6_step_k: k must be in 1..65536");
@@ -1961,6 +1845,7 @@ int r6_reset(const R6Params* params, const R6Buffers* buf, const uint8_t* mask, 
     if (b.n == 0) return 0;
     if (!b.state || !b.epconst) return fail(R6_E_BADARG, "r6_reset: state/epconst are required");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)pair_abort_word(s);   // the first call of a process is normally this one, eager: the device error word exists from here on
     if (params->obs_dim == 14)
         hipLaunchKernelGGL((r6::reset_kernel<14>), grid_for(b.n), dim3(r6::kBlock), 0, s, *params, b, mask, seed, step_index, env_offset);
     else

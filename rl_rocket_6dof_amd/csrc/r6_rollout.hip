@@ -31,6 +31,7 @@
 #include "r6_policy_device.hpp"
 
 extern "C" void r6_internal_set_error(const char* what);
+extern "C" int r6_internal_device_error_guard(const char* who, void* stream);   // r6_kernels.hip: the device error word
 
 namespace r6r {
 
@@ -191,10 +192,12 @@ __global__ __launch_bounds__(kBlock, 1) void rollout_kernel(const R6Params p, co
             // ---- finished episodes: statistics, terminal outputs, V(terminal observation) of truncated envs ----------------
             if (writer && done) {
                 if (b.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
-                if (b.fin_return) b.fin_return[env] = ep_ret;
-                if (b.fin_length) b.fin_length[env] = ep_step;
+                if (p.auto_reset) {   // terminal outputs exist under auto-reset only, as in r6_step / r6_step_k
+                    if (b.fin_return) b.fin_return[env] = ep_ret;
+                    if (b.fin_length) b.fin_length[env] = ep_step;
+                }
             }
-            if (b.final_obs && live && done) {
+            if (p.auto_reset && b.final_obs && live && done) {
                 float* dst = b.final_obs + env * OD + 8 * h;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -335,6 +338,7 @@ extern "C" int r6_rollout(const R6Params* params, const R6Buffers* buf, const R6
         return R6_E_BADARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = r6_internal_device_error_guard("r6_rollout", stream)) return rc;
 #define R6R_CASE(A, B, D, I, S) \
     if (pn.hidden1 == A && pn.hidden2 == B && p.obs_dim == D && p.integrator == I && p.shaping == S) \
         return r6r::launch<A, B, D, I, S>(p, b, pn, rk, env_seed, env_step_index, policy_seed, policy_step_index, policy_step_base, env_offset, s);

@@ -15,7 +15,7 @@ ap.add_argument("--burnin", type=int, default=2000)
 ap.add_argument("--libs", default="")
 ap.add_argument("--integrator", default="rk4")
 ap.add_argument("--wrapped", action="store_true")
-ap.add_argument("--shapes", default="base;tail=0.03125;tail=0.0625;tail=0.09375;tail=0.125;split=0.5;split=0.45;split=0.55;split=0.5,tail=0.0625")
+ap.add_argument("--shapes", default="base")
 ap.add_argument("--nocheck", action="store_true")
 ap.add_argument("--alternate", action="store_true", help="every other round walks the builds / shapes in reverse order (the first one of a round reads slow)")
 ap.add_argument("--graph", type=int, default=0, help="> 0: time replays of a HIP graph of this many captured steps instead of eager launches")
@@ -24,9 +24,8 @@ cfg = default_env_config()
 dev = torch.device("cuda:0")
 n = args.n
 libs = dict(x.split("=") for x in args.libs.split(",")) if args.libs else {"": None}
-KEYS = {"tail": "tail_frac", "tpw": "tail_tiles_per_wave", "split": "split_frac", "even": "even_xcd_share", "grid": "grid_blocks",
-        "sweep": "sweep", "flags": "sweep_flags"}
-DEFAULTS = {"tail_frac": 0.0, "tail_tiles_per_wave": 1, "split": 0, "split_frac": 0.5, "even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0}
+KEYS = {"even": "even_xcd_share", "grid": "grid_blocks", "sweep": "sweep", "flags": "sweep_flags"}
+DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0}
 
 
 def apply(shape, lib):
@@ -35,8 +34,6 @@ def apply(shape, lib):
         for kv in shape.split(","):
             k, v = kv.split("=")
             vals[KEYS[k]] = float(v)
-            if k == "split":
-                vals["split"] = 1
     for k, v in vals.items():
         _lib.tune(k, v, lib)
 

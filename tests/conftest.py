@@ -60,10 +60,10 @@ def g6():
 # Mixed tolerance used across parity tests: |a-b| <= RTOL * max(|b|, scale), with `scale` the
 # natural magnitude of the component (the reference's own state normaliser for states).
 #
-# Every call also records, per `what` (trailing indices stripped), the worst scaled error and the worst PURE relative
-# error |a-b| / |b| over the entries whose reference is not tiny (|b| >= 0.05 * scale); the session writes them to
-# gpurun_out/parity_errors.json and prints them, so that the asserted tolerances can be kept at a small multiple of
-# what is measured (a 10x numerical regression must not pass silently).
+# Every call also records, per (`what` with trailing indices stripped, asserted rtol), the worst scaled error -- the asserted
+# quantity -- and, as information only, the worst PURE relative error |a-b| / |b| over the entries whose reference is not tiny
+# (|b| >= 0.05 * scale); the session writes them to gpurun_out/parity_errors.json and prints them, so that the asserted
+# tolerances can be kept at a small multiple of what is measured (a 10x numerical regression must not pass silently).
 PARITY_LOG = {}
 
 
@@ -141,6 +141,7 @@ def _log_key(what):
     import re
 
     what = re.sub(r"^step \d+: ", "", str(what))
+    what = re.sub(r"\b(episode|rollout|step|env|case) #?\d+\b", r"\1 *", what)     # indices inside a label too
     return re.sub(r"[\s:]*(step|env|case|episode|rollout)?\s*\d+(\s+(step|env)\s*\d+)*\s*$", "", str(what)).strip()
 
 
@@ -153,9 +154,11 @@ def assert_close_scaled(a, b, scale, rtol, what=""):
     sizable = np.abs(b) >= 0.05 * scale
     pure = float((diff[sizable] / np.abs(b[sizable])).max()) if sizable.any() else 0.0
     worst = float(np.nanmax(err)) if err.size else 0.0
-    rec = PARITY_LOG.setdefault(_log_key(what), {"scaled": 0.0, "pure_rel": 0.0, "rtol": rtol, "n": 0})
-    rec["scaled"], rec["pure_rel"], rec["n"] = max(rec["scaled"], worst), max(rec["pure_rel"], pure), rec["n"] + int(err.size)
-    rec["rtol"] = min(rec["rtol"], rtol)
+    # one row per (label, asserted rtol): calls that share a label but assert different bounds never share a row, so a row's
+    # measured scaled error is always <= the bound printed next to it (round-3 review: a row keyed by label alone kept the
+    # MINIMUM rtol of its calls and could show a measured error above its "asserted" bound without any test having failed)
+    rec = PARITY_LOG.setdefault(f"{_log_key(what)} @rtol {rtol:g}", {"scaled": 0.0, "pure_rel_unasserted": 0.0, "rtol": rtol, "n": 0})
+    rec["scaled"], rec["pure_rel_unasserted"], rec["n"] = max(rec["scaled"], worst), max(rec["pure_rel_unasserted"], pure), rec["n"] + int(err.size)
     bad = ~(err <= rtol)
     if bad.any():
         i = np.unravel_index(np.nanargmax(np.where(np.isnan(err), np.inf, err)), err.shape)
@@ -180,7 +183,11 @@ def pytest_sessionfinish(session, exitstatus):
 def pytest_terminal_summary(terminalreporter):
     if not PARITY_LOG:
         return
-    terminalreporter.section("parity: worst errors measured (scaled | pure relative where |ref| >= 5 % of scale | asserted rtol)")
+    terminalreporter.section("parity: worst SCALED error measured <= asserted rtol (one row per label and bound)   [pure relative error where "
+                             "|ref| >= 5 % of scale: informational, NOT asserted by these calls -- the literal 1e-5 bounds are asserted "
+                             "by reward_rel_err / term_rel_err]")
     for k in sorted(PARITY_LOG):
         r = PARITY_LOG[k]
-        terminalreporter.write_line(f"{k[:70]:70s} {r['scaled']:.2e} | {r['pure_rel']:.2e} | {r['rtol']:.0e}  (n={r['n']})")
+        label = k.rsplit(" @rtol ", 1)[0]
+        assert r["scaled"] <= r["rtol"] or r["scaled"] != r["scaled"], (k, r)     # cannot fail: every call asserted it
+        terminalreporter.write_line(f"{label[:64]:64s} {r['scaled']:.2e} <= {r['rtol']:.0e}   [unasserted pure rel {r['pure_rel_unasserted']:.2e}]  (n={r['n']})")

@@ -8,6 +8,7 @@ state component is the reference's own observation normaliser (so the test is a 
 normalised observation error); reward-term scales are given at TERM_SCALE; the total reward's is 1.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -81,8 +82,9 @@ def _check_against_golden(env, obs, rew, done, G, P, what, tol=TOL_EVENTS):
     # cancelled sum (final_velocity +10.013 against attitude_constraint -10 ...: reward -0.218) whose terms agree to 3e-7
     pr_terms = term_rel_err(terms, G["terms"], env.reward_coefficients, TERM_SCALE)
     pr_rew = reward_rel_err(rew, G["reward"], G["terms"][:, :7])
-    rec = PARITY_LOG.setdefault(f"{what}: reward, pure relative vs max(|reward|, largest |term|)", {"scaled": 0.0, "pure_rel": 0.0, "rtol": RTOL, "n": 0})
-    rec["pure_rel"], rec["scaled"], rec["n"] = max(rec["pure_rel"], pr_rew), max(rec["scaled"], pr_rew), rec["n"] + len(rew)
+    rec = PARITY_LOG.setdefault(f"{what}: reward, PURE relative vs max(|reward|, largest |term|) @rtol {RTOL:g}",
+                                {"scaled": 0.0, "pure_rel_unasserted": 0.0, "rtol": RTOL, "n": 0})      # here the asserted quantity IS the pure relative one
+    rec["scaled"], rec["n"] = max(rec["scaled"], pr_rew), rec["n"] + len(rew)
     assert pr_terms < RTOL and pr_rew < RTOL, f"{what}: pure relative error reward terms {pr_terms:.2e} reward (vs its summands) {pr_rew:.2e}"
     print(f"[{what}] n={len(rew)} worst scaled err: state {e_state:.2e} obs {e_obs:.2e} terms {e_terms:.2e} reward {e_rew:.2e}; "
           f"pure relative: state {pr_state:.2e} obs {pr_obs:.2e} terms {pr_terms:.2e} reward vs summands {pr_rew:.2e}")
@@ -228,18 +230,47 @@ def test_g6_fixed_step_maps(torch_cuda, cfg, P, name, integ, h):
     print(f"[G6 {name}] worst scaled err {e:.2e}")
 
 
+def _fp32_drift_floor(ys, acts, h, integ, P, trials=5):
+    """What ANY float32 rollout of this trajectory drifts by, from the float64 oracle itself: the same fixed-step map in
+    float64, with the carried state rounded to float32 after every step (trial 0) or perturbed by a uniform random relative
+    error of at most half a float32 ulp per component and step (the other trials: rounding errors do not repeat between
+    implementations).  Returns the largest of the trials' worst scaled deviations from the golden float64 trajectory.  The
+    deviation is not a random walk: these flights amplify a perturbation by two orders of magnitude around a few steps (attitude
+    transients: step 391 of euler_0.04 #0, 196 of rk4_0.04 #1, 113 of rk4_0.1 #1) and let it decay again, the same steps for
+    every trial and for the GPU."""
+    from oracle import oracle_np as onp
+
+    worst = 0.0
+    m0 = float(ys[0][13])
+    for trial in range(trials):
+        rng = np.random.RandomState(100 + trial)
+        y = ys[0].astype(np.float32).astype(np.float64)
+        for k in range(len(acts)):
+            y, _ = onp.sim_step_fixed(y, onp.denormalize_action(acts[k]), m0, h, integ)
+            y = y.astype(np.float32).astype(np.float64) if trial == 0 else y * (1.0 + rng.uniform(-1, 1, 14) * 2.0 ** -24)
+            worst = max(worst, float((np.abs(y - ys[k + 1]) / np.maximum(np.abs(ys[k + 1]), P.normalizer)).max()))
+    return worst
+
+
 @pytest.mark.parametrize("name,integ,h", [("euler_0.04", "euler", 0.04), ("rk4_0.04", "rk4", 0.04), ("rk4_0.1", "rk4", 0.1)])
 def test_g6_free_running_rollouts(torch_cuda, cfg, P, name, integ, h):
+    """Free-running (not teacher-forced) fixed-step rollouts of 170-520 steps against golden G6's float64 trajectories.  The
+    expectation is derived, not a flat number (round-3 review: 1e-4 sat at 1.4x the measured 7.1e-5): a float32 rollout cannot
+    stay closer to the float64 one than the trajectory's own sensitivity to half-ulp perturbations of the state allows
+    (_fp32_drift_floor, computed here from the oracle: 1e-6 ... 8e-5 by flight); the kernel's arithmetic adds a few ulps per
+    step on top of the storage rounding, so it must stay within 4x that floor (measured on MI355X: 0.2 ... 2.3x)."""
     torch = torch_cuda
     from rl_rocket_6dof_amd import BatchedRocket6DOF
 
     g6 = load_golden("g6_fixed_step.npz")
     ys = [g6[f"roll_{name}_{r}_states"] for r in range(2)]
     acts = [g6[f"roll_{name}_{r}_actions"] for r in range(2)]
+    floors = [_fp32_drift_floor(ys[r], acts[r], h, integ, P) for r in range(2)]
     env = BatchedRocket6DOF(2, cfg, auto_reset=False, integrator=integ, timestep=h, n_substeps=1)
     env.set_state(np.stack([y[0] for y in ys]).astype(np.float32))
     nmax = max(len(a) for a in acts)
-    worst = 0.0
+    worst = [0.0, 0.0]
+    curve = [[], []]
     for k in range(nmax):
         a = np.zeros((2, 3), np.float32)
         for r in range(2):
@@ -249,8 +280,20 @@ def test_g6_free_running_rollouts(torch_cuda, cfg, P, name, integ, h):
         st = env.get_state().cpu().numpy()
         for r in range(2):
             if k < len(acts[r]):
-                worst = max(worst, assert_close_scaled(st[r], ys[r][k + 1], P.normalizer, 1e-4, f"{name} rollout {r} step {k}"))
-    print(f"[G6 rollout {name}] worst scaled drift over {nmax} steps {worst:.2e}")
+                e = assert_close_scaled(st[r], ys[r][k + 1], P.normalizer, 4.0 * floors[r], f"{name} rollout {r} step {k}")
+                curve[r].append(e)
+                worst[r] = max(worst[r], e)
+    for r in range(2):
+        print(f"[G6 rollout {name} #{r}] worst scaled drift over {len(acts[r])} steps {worst[r]:.2e} = {worst[r] / floors[r]:.2f} x the "
+              f"float32 floor of this flight ({floors[r]:.2e}); asserted <= 4 x")
+    try:      # the drift as a function of the step count (gpurun_out/g6_drift_curves.json)
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "g6_drift_curves.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[name] = {"gpu": curve, "fp32_floor": floors}
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        json.dump(data, open(path, "w"))
+    except OSError:
+        pass
 
 
 def test_velocity_shaping_vs_oracle(torch_cuda, cfg):

@@ -159,29 +159,79 @@ def test_last_only_and_bad_arguments(cfg):
         b.step_k(torch.zeros((0, 100, 3), device=b.device))
 
 
-def test_a_failed_launch_internal_wait_is_reported_by_the_next_call(cfg):
-    """step_k_pair_kernel's waits between the waves of a workgroup are bounded; one that ran out sets a word of mapped host
-    memory, and the next r6_step_k call must fail with R6_E_DEVICE instead of returning incomplete outputs silently.  The
-    kernel side is provoked by scripts/stepk_abort_check.py (an 8-poll build); here the word is set through the library's test
-    hook and the host side is checked -- and cleared again, the state is process-wide."""
+def test_a_failed_launch_internal_wait_is_reported_by_every_later_call(cfg):
+    """step_k_pair_kernel's waits between the waves of a workgroup are bounded; one that ran out raises the library's device error
+    word (mapped host memory).  From then on EVERY stepping entry point -- r6_step, r6_step_k, r6_rollout -- must fail with
+    R6_E_DEVICE, r6_device_status / r6_last_error must say so without any further call, and only r6_clear_device_error clears it.
+    The kernel side is provoked by scripts/stepk_abort_check.py (an 8-poll build); here the word is raised through the hook of the
+    -DR6_TEST_HOOKS build (csrc/variants/libr6dof_testhooks.so: the release library does not export the hook)."""
+    import ctypes as C
+    import os
+
+    import torch
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, _lib, build
+
+    release = _lib.load()
+    assert not hasattr(release, "r6_internal_test_pair_abort"), "the release library must not export the test hook"
+    if not os.path.exists(build.TEST_HOOKS_LIB):
+        pytest.skip("libr6dof_testhooks.so not built (python -m rl_rocket_6dof_amd.build --test-hooks)")
+    env = BatchedRocket6DOF(4096, cfg, integrator="euler", timestep=0.04, seed=5, lib_path=build.TEST_HOOKS_LIB)
+    lib = env.lib
+    env.reset()                               # the first eager call creates the word
+    acts = (torch.rand((4, 4096, 3), generator=torch.Generator().manual_seed(3)) * 2 - 1).to(env.device)
+    env.step_k(acts)
+    torch.cuda.synchronize()
+    assert _lib.device_status(lib) == 0
+    hook = lib.r6_internal_test_pair_abort
+    hook.argtypes, hook.restype = [C.c_int], C.c_int
+    assert hook(1) == 1
+    try:
+        assert _lib.device_status(lib) == -10003
+        assert b"bounded wait" in lib.r6_last_error()          # reported without another stepping call (e.g. after the LAST launch of a run)
+        with pytest.raises(_lib.R6Error, match="-10003"):
+            env.step_k(acts)
+        with pytest.raises(_lib.R6Error, match="-10003"):
+            env.step(acts[0])
+        env.reset()                                             # re-initialising the envs is how a caller recovers: allowed
+        assert _lib.device_status(lib) == -10003                # ... and does not clear the word by itself
+    finally:
+        assert _lib.clear_device_error(lib) == -10003
+    assert _lib.device_status(lib) == 0 and _lib.clear_device_error(lib) == 0
+    env.step_k(acts)                          # and the library works again
+    env.step(acts[0])
+    torch.cuda.synchronize()
+
+
+def test_one_buffer_for_all_steps_keeps_the_last_step(cfg):
+    """include/r6dof.h: stride 0 = 'all steps write the same buffer, as K r6_step calls would' -- the buffer must end up holding step
+    K - 1.  The three-waves-per-tile form stores the rewards of steps k and k + 1 from two different waves; with one buffer for
+    all steps the launcher must therefore take the in-order kernel (round-3 advice).  Checked through the C ABI at a size where
+    the pair form would otherwise be chosen, against K single steps."""
     import ctypes as C
 
     import torch
 
-    from rl_rocket_6dof_amd import BatchedRocket6DOF, _lib
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.params import R6Buffers, R6StepK
 
-    env = BatchedRocket6DOF(4096, cfg, integrator="euler", timestep=0.04, seed=5)
-    env.reset()
-    acts = (torch.rand((4, 4096, 3), generator=torch.Generator().manual_seed(3)) * 2 - 1).to(env.device)
-    env.step_k(acts)                          # the pair form (at most one tile per SIMD) creates the word
-    torch.cuda.synchronize()
-    hook = env.lib.r6_internal_test_pair_abort
-    hook.argtypes, hook.restype = [C.c_int], C.c_int
-    assert hook(1) == 1
-    try:
-        with pytest.raises(_lib.R6Error, match="-10003"):
-            env.step_k(acts)
-    finally:
-        assert hook(0) == 1
-    env.step_k(acts)                          # and the library works again
-    torch.cuda.synchronize()
+    n, K = 4096, 9
+    a = BatchedRocket6DOF(n, cfg, integrator="euler", timestep=0.04, seed=21, record_terms=True)
+    b = BatchedRocket6DOF(n, cfg, integrator="euler", timestep=0.04, seed=21, record_terms=True)
+    a.reset()
+    b.reset()
+    _seed_low_altitude(a, b)
+    acts = (torch.rand((K, n, 3), generator=torch.Generator().manual_seed(5)) * 2 - 1).to(a.device)
+    for rep in range(20):                     # a race would not show every time
+        for k in range(K):
+            o, r, d, _ = a.step(acts[k])
+        buf = R6Buffers.from_buffer_copy(b._buf)
+        buf.action = acts.data_ptr()
+        sk = R6StepK(k=K, flags=0, action_stride=n * 3)          # every output stride 0: the env's own single-step buffers
+        rc = b.lib.r6_step_k(C.byref(b.params), C.byref(buf), C.byref(sk), b._seed, b._step_count + 1, b.env_offset, b._stream())
+        assert rc == 0, b.lib.r6_last_error()
+        b._step_count += K
+        torch.cuda.synchronize()
+        assert torch.equal(b.reward, r), f"rep {rep}: the reward buffer does not hold the last step"
+        assert torch.equal(b.terms[:, :n], a.terms[:, :n]) and torch.equal(b.obs, o) and torch.equal(b.done, a.done)
+        assert torch.equal(a.state, b.state)
