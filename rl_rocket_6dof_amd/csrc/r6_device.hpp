@@ -478,6 +478,71 @@ constexpr float P[7][4] = {{1.0f, (float)-2.8535800653862835, (float)3.071743464
                            {0, (float)1.3824689317781436, (float)-3.7649378635562871, (float)2.3824689317781438}};
 constexpr float kRtol = 1e-3f, kAtol = 1e-6f;
 constexpr float kSafety = 0.9f, kMinFactor = 0.2f, kMaxFactor = 10.0f;
+
+// The stage vectors hold only the components whose derivative is not known without evaluating forces: v (3), q (4),
+// omega_y, omega_z -- D = 9 of the 14.  The rest follows exactly: d(mass)/dt = -mdot is constant, d(omega_x)/dt == 0 (rhs_dyn),
+// and d(r)/dt of stage j is that stage's velocity ARGUMENT, v + h sum_m A[j][m] Kv[m] -- so every place where the method takes
+// a linear combination of the stages' position rows (stage arguments, y_new, error estimate, dense output) becomes
+//     (sum of the weights) v + h sum_m (weights . A[., m]) Kv[m]
+// with the coefficient products below, formed once at compile time in double precision.  (Round 3 kept all 7 x 13 stage values:
+// 254-256 VGPRs, two waves per SIMD.)
+constexpr int D = 9;
+struct Derived {
+    float AA[6][5];   // stage st, position: r + h (C[st] v + h sum_m AA[st][m] Kv[m])
+    float BA[5];      // y_new, position:     r + h (v + h sum_m BA[m] Kv[m])                         (sum B = 1)
+    float EA[6];      // error estimate, position rows: h sum_m EA[m] Kv[m]                            (sum E = 0); the f(y_new) row enters through B
+    float PS[4];      // dense output, position rows: sum_j P[j][k]  (= 1, 0, 0, 0 up to round-off)
+    float PA[6][4];   // dense output, position rows: h sum_m PA[m][k] Kv[m]
+};
+constexpr Derived make_derived() {
+    constexpr double a[6][5] = {{0, 0, 0, 0, 0},
+                                {1.0 / 5, 0, 0, 0, 0},
+                                {3.0 / 40, 9.0 / 40, 0, 0, 0},
+                                {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+                                {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+                                {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+    constexpr double bw[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+    constexpr double e[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+    constexpr double pm[7][4] = {{1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+                                 {0, 0, 0, 0},
+                                 {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+                                 {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+                                 {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+                                 {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+                                 {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+    Derived t{};
+    for (int st = 0; st < 6; ++st)
+        for (int m = 0; m < 5; ++m) {
+            double acc = 0;
+            for (int j = m + 1; j < st; ++j) acc += a[st][j] * a[j][m];
+            t.AA[st][m] = (float)acc;
+        }
+    for (int m = 0; m < 5; ++m) {
+        double acc = 0;
+        for (int j = m + 1; j < 6; ++j) acc += bw[j] * a[j][m];
+        t.BA[m] = (float)acc;
+    }
+    for (int m = 0; m < 6; ++m) {
+        double acc = e[6] * bw[m];
+        for (int j = m + 1; j < 6; ++j) acc += e[j] * a[j][m];
+        t.EA[m] = (float)acc;
+    }
+    for (int k = 0; k < 4; ++k) {
+        double acc = 0;
+        for (int j = 0; j < 7; ++j) acc += pm[j][k];
+        t.PS[k] = (float)acc;
+    }
+    for (int m = 0; m < 6; ++m)
+        for (int k = 0; k < 4; ++k) {
+            double acc = pm[6][k] * bw[m];
+            for (int j = m + 1; j < 6; ++j) acc += pm[j][k] * a[j][m];
+            t.PA[m][k] = (float)acc;
+        }
+    return t;
+}
+constexpr Derived T = make_derived();
+// component of the 13-vector behind stage-vector slot d
+__device__ __forceinline__ constexpr int comp(int d) { return d < 7 ? 3 + d : 4 + d; }   // 3,4,5 | 6,7,8,9 | 11,12
 }  // namespace dp45
 
 // One env step [0, dt] of the adaptive integrator.  Returns status (0 reached dt, 1 ground event,
@@ -486,37 +551,61 @@ constexpr float kSafety = 0.9f, kMinFactor = 0.2f, kMaxFactor = 10.0f;
 __device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J, float dt,
                                               int& nfev) {
     using namespace dp45;
-    float K[S][kDyn];
+    float K[6][D];    // stages 1..6 of the step in progress; K[0] = f(y) (FSAL: f(y_new) of the step before)
+    float Kn[D];      // f(y_new)
     float ynew[kDyn];
     const float mdot = c.mdot;
     auto sq = [](float v) { return v * v; };
+    // the force / torque / kinematics part of the RHS at state `ya` (only ya[0], ya[3..12] are read), into a stage vector
+    auto eval = [&](const float (&ya)[kDyn], float im, float (&k)[D]) __attribute__((always_inline)) {
+        float dv[3], dw[2], dq[4];
+        rhs_dyn(ya, im, c, J, dv, dw);
+        rhs_quat(ya, dq);
+        k[0] = dv[0];
+        k[1] = dv[1];
+        k[2] = dv[2];
+        k[3] = dq[0];
+        k[4] = dq[1];
+        k[5] = dq[2];
+        k[6] = dq[3];
+        k[7] = dw[0];
+        k[8] = dw[1];
+    };
 
-    rhs13(y, frcp(mass), c, J, K[0]);
+    eval(y, frcp(mass), K[0]);
     nfev = 1;
     // ---- select_initial_step (common.py) --------------------------------------------------------------
     float h_abs;
     {
         float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < kDyn; ++i) {
+        for (int i = 0; i < kDyn; ++i) {   // the 13 dynamic components: derivative = v for r, K[0] for v / q / omega_yz, 0 for omega_x
             const float isc = frcp(fmaf(fabsf(y[i]), kRtol, kAtol));
             d0 += sq(y[i] * isc);
-            d1 += sq(K[0][i] * isc);
+            const float f0 = (i < 3) ? y[3 + i] : ((i == 10) ? 0.0f : K[0][i < 10 ? i - 3 : i - 4]);
+            d1 += sq(f0 * isc);
         }
         const float iscm = frcp(fmaf(fabsf(mass), kRtol, kAtol));
-        d0 = sqrtf((d0 + sq(mass * iscm)) * (1.0f / 14.0f));
-        d1 = sqrtf((d1 + sq(mdot * iscm)) * (1.0f / 14.0f));
-        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        // (hardware square root / reciprocal / exp2 / log2, 1 ulp: the step-size control needs no more, and the IEEE-exact forms --
+        //  sqrtf, /, powf -- were a fifth of the instructions of an attempt)
+        d0 = fsqrt((d0 + sq(mass * iscm)) * (1.0f / 14.0f));
+        d1 = fsqrt((d1 + sq(mdot * iscm)) * (1.0f / 14.0f));
+        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 * frcp(d1);
         h0 = fminf(h0, dt);
 #pragma unroll
-        for (int i = 0; i < kDyn; ++i) ynew[i] = fmaf(h0, K[0][i], y[i]);
-        rhs13(ynew, frcp(fmaf(-mdot, h0, mass)), c, J, K[1]);
+        for (int i = 0; i < 3; ++i) ynew[i] = fmaf(h0, y[3 + i], y[i]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) ynew[comp(d)] = fmaf(h0, K[0][d], y[comp(d)]);
+        ynew[10] = y[10];
+        eval(ynew, frcp(fmaf(-mdot, h0, mass)), Kn);
         nfev = 2;
         float d2 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < kDyn; ++i) d2 += sq((K[1][i] - K[0][i]) * frcp(fmaf(fabsf(y[i]), kRtol, kAtol)));
-        d2 = sqrtf(d2 * (1.0f / 14.0f)) / h0;
-        const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+        for (int i = 0; i < 3; ++i) d2 += sq((ynew[3 + i] - y[3 + i]) * frcp(fmaf(fabsf(y[i]), kRtol, kAtol)));   // f1 - f0 of the position rows
+#pragma unroll
+        for (int d = 0; d < D; ++d) d2 += sq((Kn[d] - K[0][d]) * frcp(fmaf(fabsf(y[comp(d)]), kRtol, kAtol)));
+        d2 = fsqrt(d2 * (1.0f / 14.0f)) * frcp(h0);
+        const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : fexp2(0.2f * flog2(0.01f * frcp(fmaxf(d1, d2))));
         h_abs = fminf(fminf(100.0f * h0, h1), dt);
     }
 
@@ -536,46 +625,74 @@ __device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, con
             }
             h = fminf(h_abs, dt - t);
             h_abs = h;
+            const float hh = h * h;
             // ---- rk_step (rk.py): stages 1..5, y_new, f_new --------------------------------------------
 #pragma unroll
             for (int st = 1; st < 6; ++st) {
                 float ys[kDyn];
-#pragma unroll
-                for (int i = 0; i < kDyn; ++i) {
+                {   // altitude (the only position the forces read): x + h C v_x + h^2 sum_m AA[st][m] Kv_x[m]
                     float acc = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < st; ++j) acc = fmaf(A[st][j], K[j][i], acc);
-                    ys[i] = fmaf(h, acc, y[i]);
+                    for (int m = 0; m + 1 < st; ++m) acc = fmaf(T.AA[st][m], K[m][0], acc);
+                    ys[0] = fmaf(hh, acc, fmaf(h * C[st], y[3], y[0]));
+                    ys[1] = ys[2] = 0.0f;   // never read
                 }
-                rhs13(ys, frcp(fmaf(-mdot, t + C[st] * h, mass)), c, J, K[st]);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < st; ++j) acc = fmaf(A[st][j], K[j][d], acc);
+                    ys[comp(d)] = fmaf(h, acc, y[comp(d)]);
+                }
+                ys[10] = y[10];
+                eval(ys, frcp(fmaf(-mdot, t + C[st] * h, mass)), K[st]);
             }
 #pragma unroll
-            for (int i = 0; i < kDyn; ++i) {
+            for (int i = 0; i < 3; ++i) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc = fmaf(B[j], K[j][i], acc);
-                ynew[i] = fmaf(h, acc, y[i]);
+                for (int m = 0; m < 5; ++m) acc = fmaf(T.BA[m], K[m][i], acc);
+                ynew[i] = fmaf(hh, acc, fmaf(h, y[3 + i], y[i]));
             }
-            rhs13(ynew, frcp(fmaf(-mdot, t + h, mass)), c, J, K[6]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = fmaf(B[j], K[j][d], acc);
+                ynew[comp(d)] = fmaf(h, acc, y[comp(d)]);
+            }
+            ynew[10] = y[10];
+            eval(ynew, frcp(fmaf(-mdot, t + h, mass)), Kn);
             nfev += 6;
             // ---- error norm ------------------------------------------------------------------------------
             float en = 0.0f;
 #pragma unroll
-            for (int i = 0; i < kDyn; ++i) {
+            for (int i = 0; i < 3; ++i) {   // position rows: h^2 sum_m EA[m] Kv[m]
                 float e = 0.0f;
 #pragma unroll
-                for (int j = 0; j < S; ++j) e = fmaf(E[j], K[j][i], e);
+                for (int m = 0; m < 6; ++m) e = fmaf(T.EA[m], K[m][i], e);
                 const float sc = fmaf(fmaxf(fabsf(y[i]), fabsf(ynew[i])), kRtol, kAtol);
-                en += sq(e * h / sc);
+                en += sq(e * hh * frcp(sc));
             }
-            en = sqrtf(en * (1.0f / 14.0f));   // the mass component contributes 0 to the sum, 1 to the count
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                float e = E[6] * Kn[d];
+#pragma unroll
+                for (int j = 5; j >= 0; --j) e = fmaf(E[j], K[j][d], e);
+                const float sc = fmaf(fmaxf(fabsf(y[comp(d)]), fabsf(ynew[comp(d)])), kRtol, kAtol);
+                en += sq(e * h * frcp(sc));
+            }
+            // en = error_norm^2 (omega_x and the mass contribute 0 to the sum, 1 each to the count); norm < 1 <=> en < 1, and
+            // norm^-1/5 = en^-1/10 = exp2(-0.1 log2 en)  (en == 0: exp2(+inf) = inf, cut to kMaxFactor like scipy's special case)
+            en *= (1.0f / 14.0f);
+            const float pw = kSafety * fexp2(-0.1f * flog2(en));
             if (en < 1.0f) {
-                float factor = (en == 0.0f) ? kMaxFactor : fminf(kMaxFactor, kSafety * powf(en, -0.2f));
+                float factor = fminf(kMaxFactor, pw);
                 if (rejected) factor = fminf(1.0f, factor);
                 h_abs *= factor;
                 accepted = true;
             } else {
-                h_abs *= fmaxf(kMinFactor, kSafety * powf(en, -0.2f));
+                h_abs *= fmaxf(kMinFactor, pw);
                 rejected = true;
             }
         }
@@ -585,33 +702,50 @@ __device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, con
         }
         // ---- terminal event on the accepted sub-step (ivp.py find_active_events / handle_events) ---------
         if (crossing(y[0], ynew[0])) {
-            // x(s) = x_old + h (Q0 s + Q1 s^2 + Q2 s^3 + Q3 s^4), Q = K^T P
-            float q[4] = {0, 0, 0, 0};
+            // y(s) = y_old + h s (Q0 + Q1 s + Q2 s^2 + Q3 s^3), Q = K^T P; position rows through PS / PA (see Derived)
+            auto q_pos = [&](int i, float (&qq)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < S; ++j) {
+                for (int k = 0; k < 4; ++k) {
+                    float acc = 0.0f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) q[m] = fmaf(K[j][0], P[j][m], q[m]);
-            }
+                    for (int m = 0; m < 6; ++m) acc = fmaf(T.PA[m][k], K[m][i], acc);
+                    qq[k] = fmaf(h, acc, T.PS[k] * y[3 + i]);
+                }
+            };
+            float q[4];
+            q_pos(0, q);
             const float cx[5] = {y[0], h * q[0], h * q[1], h * q[2], h * q[3]};
             const float th = poly_root01(cx, y[0], ynew[0]);
+            float yev[kDyn];
 #pragma unroll
-            for (int i = 0; i < kDyn; ++i) {
+            for (int i = 0; i < 3; ++i) {
+                float qq[4];
+                q_pos(i, qq);
+                yev[i] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[i]);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
                 float qq[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < S; ++j) {
+                for (int j = 0; j < 6; ++j) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) qq[m] = fmaf(K[j][i], P[j][m], qq[m]);
+                    for (int k = 0; k < 4; ++k) qq[k] = fmaf(K[j][d], P[j][k], qq[k]);
                 }
-                y[i] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[i]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qq[k] = fmaf(Kn[d], P[6][k], qq[k]);
+                yev[comp(d)] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[comp(d)]);
+            }
+#pragma unroll
+            for (int i = 0; i < kDyn; ++i) {
+                if (i != 10) y[i] = yev[i];
             }
             t += th * h;
             status = 1;
         } else {
 #pragma unroll
-            for (int i = 0; i < kDyn; ++i) {
-                y[i] = ynew[i];
-                K[0][i] = K[6][i];   // FSAL
-            }
+            for (int i = 0; i < kDyn; ++i) y[i] = ynew[i];
+#pragma unroll
+            for (int d = 0; d < D; ++d) K[0][d] = Kn[d];   // FSAL
             t += h;
         }
     }

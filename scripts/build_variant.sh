@@ -1,12 +1,27 @@
 #!/bin/bash
-# usage: scripts/build_variant.sh <name> [extra hipcc flags...]   -> rl_rocket_6dof_amd/csrc/variants/libr6dof_<name>.so
-# A/B builds of the kernel library from the SAME sources with -D switches; scripts/kbench.py --libs name=path,... times
-# them interleaved in one process.  (*.so is git-ignored but travels to the GPU box with gpurun.)
+# usage: scripts/build_variant.sh [--all] <name> [extra hipcc flags...]   -> rl_rocket_6dof_amd/csrc/variants/libr6dof_<name>.so
+# A/B builds of the kernel library from the SAME sources with -D switches; scripts/launch_shape_ab.py / kbench.py --libs
+# name=path,... time them interleaved in one process.  Only r6_kernels.hip is recompiled with the flags (the other units are the
+# release objects of `python -m rl_rocket_6dof_amd.build`); --all recompiles every unit with them.
+# (*.so is git-ignored but travels to the GPU box with gpurun.)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ALL=0
+if [ "$1" == "--all" ]; then ALL=1; shift; fi
 NAME=$1; shift
-OUT=$ROOT/rl_rocket_6dof_amd/csrc/variants
-mkdir -p $OUT
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -fno-math-errno -fno-slp-vectorize -Wall -Wno-unused-function \
-  -Wl,-Bsymbolic "$@" $ROOT/rl_rocket_6dof_amd/csrc/r6_kernels.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_policy.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_ppo_update.hip $ROOT/rl_rocket_6dof_amd/csrc/r6_rollout.hip -o $OUT/libr6dof_$NAME.so
+C=$ROOT/rl_rocket_6dof_amd/csrc
+OUT=$C/variants
+OBJ=$C/build/variant_$NAME
+mkdir -p $OUT $OBJ
+FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-math-errno -fno-slp-vectorize -Wall -Wno-unused-function"
+python3 -m rl_rocket_6dof_amd.build > /dev/null
+if [ $ALL == 1 ]; then UNITS="r6_kernels r6_policy r6_ppo_update r6_rollout"; else UNITS="r6_kernels"; fi
+PIDS=""
+for u in $UNITS; do hipcc $FLAGS "$@" -c $C/$u.hip -o $OBJ/$u.o 2> $OBJ/$u.log & PIDS="$PIDS $!"; done
+for p in $PIDS; do wait $p; done
+OBJS=""
+for u in r6_kernels r6_policy r6_ppo_update r6_rollout; do
+  if [ -f $OBJ/$u.o ] && [[ " $UNITS " == *" $u "* ]]; then OBJS="$OBJS $OBJ/$u.o"; else OBJS="$OBJS $C/build/release/$u.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic $OBJS -o $OUT/libr6dof_$NAME.so
 echo $OUT/libr6dof_$NAME.so

@@ -50,26 +50,29 @@ gen = torch.Generator(device=dev).manual_seed(1)
 pool = [(torch.rand((n, 3), generator=gen, device=dev) * 2 - 1) for _ in range(2)]
 
 if not args.nocheck:
-    # bit-exactness: every shape against "base", 300 steps from reset (covers the first landing wave when wrapped / the reset queue)
+    # bit-exactness: every (build, shape) against the first one, 300 steps from reset (covers the first landing wave when wrapped / the resets)
     ref = None
-    for sh in shapes:
-        e = make(next(iter(libs)))
-        apply(sh, e.lib)
-        e.reset()
-        for k in range(300):
-            e.step_async(pool[k % 2])
-        torch.cuda.synchronize()
-        snap = (e.state.clone(), e.obs.clone(), e.reward.clone(), e.done.clone(), e.epconst.clone())
-        if e.stats is not None:
-            snap += (e.stats.sum(0).clone(),)
-        if ref is None:
-            ref = snap
-        else:
-            ok = all(torch.equal(a, b) for a, b in zip(ref[:5], snap[:5]))
-            st = "" if len(snap) == 5 else f" stats(count) equal: {bool(ref[5][0] == snap[5][0])} sums rel diff {float(((ref[5] - snap[5]).abs() / ref[5].abs().clamp_min(1)).max()):.2e}"
-            print(f"bit-exact {sh:32s}: {ok}{st}", flush=True)
-            assert ok, sh
-        del e
+    for l in libs:
+        for sh in shapes:
+            e = make(l)
+            apply(sh, e.lib)
+            e.reset()
+            for k in range(300):
+                e.step_async(pool[k % 2])
+            torch.cuda.synchronize()
+            snap = (e.state.clone(), e.obs.clone(), e.reward.clone(), e.done.clone(), e.epconst.clone())
+            if e.stats is not None:
+                snap += (e.stats.sum(0).clone(),)
+            if ref is None:
+                ref = snap
+            else:
+                ok = all(torch.equal(a, b) for a, b in zip(ref[:5], snap[:5]))
+                st = "" if len(snap) == 5 else f" stats equal: {bool(torch.equal(ref[5], snap[5]))}"
+                print(f"bit-exact {l or 'intree':10s} {sh:32s}: {ok}{st}", flush=True)
+                assert ok, (l, sh)
+                assert len(snap) == 5 or torch.equal(ref[5], snap[5]), (l, sh, "stats")
+            apply("base", e.lib)
+            del e
     torch.cuda.empty_cache()
 
 envs = {l: make(l) for l in libs}
