@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_RAW = 189
 BYTES_WRAPPED = 201            # obs 13 floats (-4 B), ep_step r+w (+8), ep_return r+w (+8)
-TRAFFIC_PROFILE = os.path.join("profiles", "r3_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r4_pmc_traffic.json")
 
 
 def bytes_per_env_step(variant: str, k: int = 1, obs_dim: int = 14) -> float:
@@ -253,60 +253,79 @@ def traffic_from_profile(variant: str, integrator: str, n: int, k: int):
         return None, None
 
 
-VALU_PROFILE = os.path.join("profiles", "r3_pmc_valu.json")
-SIMDS, ENGINE_CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+VALU_PROFILE = os.path.join("profiles", "r4_pmc_valu.json")
+SIMDS = 1024                               # 256 CUs x 4 SIMDs
+# Measured issue cost of a wave64 vector instruction per SIMD once two or more waves are ready (scripts/valu_operand_bench.hip,
+# profiles/r3_experiments.json): vector / constant sources 1.2 ns, a scalar-register (SGPR / vcc) source 1.8 ns, a transcendental
+# 3.4 ns.  (SQ_ACTIVE_INST_VALU counts a quad-cycle per instruction; pricing an instruction at those 4 cycles, as round 3's line
+# did, overstates the pipe's occupancy by 1.5-2x.)
+VALU_NS_PLAIN, VALU_NS_SCALAR_SRC, VALU_NS_TRANS = 1.2, 1.8, 3.4
+SCALAR_SRC_SHARE_HOT_LOOP = 0.15           # static share of the tile loop's vector instructions with an SGPR / vcc source (scripts/valu_mix.py)
+
+
+def valu_issue_time_us(insts_per_launch: float, trans_per_launch: float, simds: int = SIMDS) -> dict:
+    """Per-SIMD VALU issue time of a launch at the measured rates: a floor (every instruction at the plain rate) and the priced
+    figure (transcendentals and the scalar-source share at their own rates)."""
+    lo = insts_per_launch * VALU_NS_PLAIN / simds * 1e-3
+    hi = (insts_per_launch * VALU_NS_PLAIN + trans_per_launch * (VALU_NS_TRANS - VALU_NS_PLAIN) +
+          SCALAR_SRC_SHARE_HOT_LOOP * insts_per_launch * (VALU_NS_SCALAR_SRC - VALU_NS_PLAIN)) / simds * 1e-3
+    return {"floor_us": lo, "priced_us": hi}
 
 
 def valu_from_profile(variant: str, integrator: str, n: int, k: int, kernel_ms: float):
-    """The kernel's OTHER resource next to HBM: VALU instructions per launch x 4 cycles as a share of the launch, from the
-    committed PMC pass of THIS workload (SQ_ACTIVE_INST_VALU, quad-cycles per launch; scripts/pmc.sh) and this run's kernel
-    time.  A file constant like `traffic`; see the note in the object for what the figure is and is not."""
+    """The kernel's OTHER resource next to HBM: the time one SIMD needs to ISSUE the launch's vector instructions, from the
+    instruction counts of the committed PMC pass of THIS workload (SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32; scripts/pmc.sh) priced at
+    the measured issue rates, as a share of this run's kernel time.  A file constant like `traffic`."""
     path = os.path.join(ROOT, VALU_PROFILE)
     if not (os.path.exists(path) and variant == "raw" and integrator == "rk4" and n == (1 << 20) and k == 1 and kernel_ms > 0):
         return None
     try:
         prof = json.load(open(path))
-        active = float(prof["raw_per_launch"]["SQ_ACTIVE_INST_VALU"])
-        return {"busy_frac": 4.0 * active / SIMDS / (ENGINE_CLOCK_HZ * kernel_ms * 1e-3),
+        raw = prof["raw_per_launch"]
+        insts = float(raw["SQ_INSTS_VALU"])
+        trans = float(raw.get("SQ_INSTS_VALU_TRANS_F32", 0.052 * insts))
+        t = valu_issue_time_us(insts, trans)
+        return {"issue_time_us_per_simd": t["priced_us"], "issue_time_floor_us_per_simd": t["floor_us"],
+                "share_of_launch": t["priced_us"] / (kernel_ms * 1e3),
                 "instructions_per_64_env_tile": prof["derived"]["valu_instructions_per_64_env_tile"],
-                "source": f"{VALU_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); engine clock "
-                          f"assumed at its {ENGINE_CLOCK_HZ / 1e9:.1f} GHz peak",
-                "busy_frac_at_2.1GHz": 4.0 * active / SIMDS / (2.1e9 * kernel_ms * 1e-3),
-                "note": "SQ_ACTIVE_INST_VALU counts one quad-cycle per VALU instruction, so busy_frac is the share of the launch at "
-                        "FOUR cycles per instruction -- an upper bound of the pipe's occupancy: a microbenchmark (scripts/valu_operand_bench.hip, "
-                        "profiles/r3_experiments.json) issues a wave64 VALU instruction with vector / constant sources every 1.2 ns per SIMD once "
-                        "two waves are ready (1.8 ns with a scalar-register source, 3.4 ns transcendental), which makes this kernel's VALU work "
-                        "about 21 us next to a 30.6 us memory skeleton: the launch is bounded by how the two overlap (3 of 5 waves per SIMD "
-                        "alive on average), not by either alone; shader clock under the kernel 2.03-2.21 GHz (clock probe)"}
+                "mean_resident_waves_per_simd": prof["derived"].get("mean_resident_waves_per_simd (SQ_WAVE_CYCLES * 4 / 1024 / kernel cycles)"),
+                "pricing_ns_per_instruction": {"vector_or_constant_sources": VALU_NS_PLAIN, "scalar_register_source": VALU_NS_SCALAR_SRC,
+                                               "transcendental": VALU_NS_TRANS, "scalar_source_share_assumed": SCALAR_SRC_SHARE_HOT_LOOP},
+                "source": f"{VALU_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); rates: scripts/valu_operand_bench.hip",
+                "note": "the launch is bounded by how its memory time (30.6 us for the same accesses without arithmetic) and this issue "
+                        "time overlap, not by either alone: ~3 of the 5 resident waves per SIMD are alive on average"}
     except Exception:
         return None
 
 
-STEPK_PROFILE = os.path.join("profiles", "r3_pmc_stepk.json")
+STEPK_PROFILE = os.path.join("profiles", "r4_pmc_stepk.json")
 
 
 def small_batch_bound(n: int, integrator: str, dt, k: int, launch_s: float) -> dict:
-    """BASELINE configs[1] (65 536 envs = 1024 tiles on 1024 SIMDs): the launch is bounded by what one SIMD can issue for its one
-    tile (r6::step_k_pair_kernel: a dynamics wave and two reward waves per tile), not by HBM.  VALU issue share of a launch = 4 x SQ_ACTIVE_INST_VALU (quad-cycles per launch, committed PMC pass of this
-    workload, scripts/pmc_stepk.sh) / 1024 SIMDs / (2.4 GHz x this run's launch time); for a launch shape without a PMC pass
-    only the bound's name is reported."""
+    """BASELINE configs[1] (65 536 envs = 1024 tiles on 1024 SIMDs): a launch is bounded by the DEPENDENT chain of one tile's K
+    steps on its SIMD (r6::step_k_pair_kernel: a dynamics wave and two reward waves per tile), not by HBM and not by VALU issue:
+    the committed PMC pass of this workload (scripts/pmc_stepk.sh) has the waves waiting (s_waitcnt / sleep: a partner's result, a
+    load) for about half of their cycles.  Reported: the share of the launch one SIMD needs to issue the tile's vector instructions
+    at the measured rates (see valu_issue_time_us) and the profile's split of the wave cycles."""
     if k <= 1:
         return {"bound": "launch_latency", "launch_us": launch_s * 1e6,
                 "note": "one r6_step launch per env step: launch-to-launch time of a kernel whose tiles (one per wave) take one pass; the "
                         "memory time of the step is ~1.5 us, its one-wave-per-SIMD compute ~5 us -- r6_step_k amortises the rest"}
-    out = {"bound": "valu_issue_of_one_simd_per_tile", "unit": "share of the launch in which a SIMD issues a VALU instruction",
+    out = {"bound": "dependent_chain_of_one_tile_per_simd", "unit": "share of the launch in which a SIMD issues vector instructions (measured issue rates)",
            "peak": 1.0, "launch_us": launch_s * 1e6}
     path = os.path.join(ROOT, STEPK_PROFILE)
     if os.path.exists(path) and n == 65536 and integrator == "euler" and k == 16:
         try:
             prof = json.load(open(path))
-            active = float(prof["raw_per_launch"]["SQ_ACTIVE_INST_VALU"])
-            out["achieved"] = 4.0 * active / SIMDS / (ENGINE_CLOCK_HZ * launch_s)
+            raw = prof["raw_per_launch"]
+            t = valu_issue_time_us(float(raw["SQ_INSTS_VALU"]), float(raw.get("SQ_INSTS_VALU_TRANS_F32", 0.0)))
+            out["achieved"] = t["priced_us"] / (launch_s * 1e6)
             out["frac"] = out["achieved"]
+            out["valu_issue_time_us_per_simd"] = t["priced_us"]
             out["valu_instructions_per_tile_and_env_step"] = prof["derived"]["valu_instructions_per_tile_and_env_step"]
             out["kernel"] = prof.get("kernel")
             out["share_of_wave_cycles"] = prof["derived"]["share_of_wave_cycles"]
-            out["source"] = f"{STEPK_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); engine clock taken at its 2.4 GHz peak"
+            out["source"] = f"{STEPK_PROFILE} (static file, PMC passes at commit {prof.get('commit', 'unrecorded')}); rates: scripts/valu_operand_bench.hip"
         except Exception:
             pass
     return out

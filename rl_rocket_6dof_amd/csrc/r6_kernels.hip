@@ -66,12 +66,7 @@ constexpr int kWaves = kBlock / 64;
 #define R6_EARLY_LOAD 1         // A/B switch (RK4 / RK45 instances): rotated tile loop, first tile requested before the set-up barrier
 #endif
 constexpr int kResetQueueCap = R6_RESET_QUEUE;
-#ifndef R6_RESET_INLOOP
-#define R6_RESET_INLOOP 0       // A/B switch: 1 = finished envs are re-sampled by their own wave while it waits for its next tile (no queue, no
-                                // workgroup barrier, no drain at the end of the launch); 0 = round 1-3's dense drain of a per-workgroup LDS queue
-#endif
-// s_waitcnt simm16 of gfx9 with only vmcnt set (expcnt / lgkmcnt left at "do not wait"): vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14
-constexpr int vmcnt_only(int v) { return (v & 15) | ((v >> 4) << 14) | 0x0F70; }
+constexpr int kDynCounters = 32, kDynStride = 32;   // last-round hand-out: counters, and dwords between two of them (128 B: a line each)
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS instructions of one wave execute in order; this only stops the compiler from moving
@@ -105,6 +100,10 @@ __device__ __forceinline__ gptr<T> uniform_ptr(T* p) {
 #ifndef R6_NT_MIN_ENVS
 #define R6_NT_MIN_ENVS (3ll << 21)
 #endif
+#ifndef R6_NT_WINDOW_LO
+#define R6_NT_WINDOW_LO 1200000ll
+#define R6_NT_WINDOW_HI 2360000ll
+#endif
 template <bool NT, typename T, typename V>
 __device__ __forceinline__ void stream_store(gptr<T> p, V v) {
     if constexpr (NT) __builtin_nontemporal_store((T)v, p);
@@ -118,49 +117,16 @@ __device__ __forceinline__ void stream_store(gptr<T> p, V v) {
 // R6Buffers kernel argument 1 right behind it (both are 8-byte multiples).
 typedef const __attribute__((address_space(4))) char* kernarg_ptr_t;
 static_assert(sizeof(R6Params) % 8 == 0, "R6Buffers must follow R6Params without padding");
-// OFF: bytes of kernel arguments in front of R6Params (step_kernel's hot scalars, below; 0 for the other kernels)
-template <int OFF = 0>
 __device__ __forceinline__ R6Params load_params() {
     kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
-    return *(const R6Params*)(k + OFF);
+    return *(const R6Params*)k;
 }
-template <int OFF = 0>
 __device__ __forceinline__ R6Buffers load_buffers() {
     kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
-    return *(const R6Buffers*)(k + OFF + sizeof(R6Params));
+    return *(const R6Buffers*)(k + sizeof(R6Params));
 }
-
-// step_kernel's HOT kernel arguments: what a wave needs before it can request its first tile -- the row pointers of the inputs,
-// the shard size, the tile-list parameters.  They are the kernel's FIRST arguments, as plain scalars, and the translation unit is
-// built with -mllvm -amdgpu-kernarg-preload-count=16: the command processor then hands them to every wave in SGPRs at launch
-// (gfx950 kernarg preload), and the first loads of the launch no longer wait for a scalar-load round trip to a kernarg segment
-// that no cache holds yet (the host wrote it a moment ago).  Everything else (R6Params, R6Buffers behind them) is read where it is
-// needed, as before.  Mirror of the argument list, for the offsets of the by-value structs in the kernarg segment:
-#ifndef R6_HOT_ARGS
-#define R6_HOT_ARGS 0
-#endif
-struct HotArgs {
-    float* state;
-    const float* epconst;
-    const float* action;
-    uint32_t* ep_step;
-    float* ep_return;
-    int32_t n, ld;
-    uint32_t share_sweep, n_blocks;   // even-XCD share (q16, < 65536) | tile-order bits << 16: 14 dwords in all = what the 16 user SGPRs hold next to the kernarg pointer
-};
-struct StepKernargMirror {
-    HotArgs hot;
-    R6Params p;
-    R6Buffers b;
-};
-#if R6_HOT_ARGS
-constexpr int kStepParamsOff = (int)offsetof(StepKernargMirror, p);
-static_assert(offsetof(StepKernargMirror, b) == kStepParamsOff + sizeof(R6Params), "R6Buffers follows R6Params");
-#else
-constexpr int kStepParamsOff = 0;
-#endif
 
 // env:180-199 for one env, written straight to HBM (used by the dense drain of the reset queue).
 template <int OD>
@@ -213,8 +179,8 @@ struct TileIn {
     uint32_t ep_step;
 };
 
-template <int SHAPING, bool FULL, typename BUF>
-__device__ __forceinline__ void load_tile(const BUF& b, bool has_ep, int64_t e0, int lane, TileIn& in, float* lds = nullptr) {
+template <int SHAPING, bool FULL>
+__device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64_t e0, int lane, TileIn& in, float* lds = nullptr) {
     const int64_t ld = b.ld;
     const bool live = FULL ? true : (lane < b.n - e0);
     in.mass = in.m0 = 4.0e4f;
@@ -271,7 +237,7 @@ __device__ __forceinline__ void load_tile(const BUF& b, bool has_ep, int64_t e0,
 #define R6_RK4_WAVES 5
 #endif
 #ifndef R6_RK45_WAVES
-#define R6_RK45_WAVES 4    // waves per SIMD the adaptive instances are compiled for (register budget 512 / waves)
+#define R6_RK45_WAVES 4    // waves per SIMD the adaptive instances are compiled for (128 registers; round 3: 1 -> 254 registers, two waves)
 #endif
 #ifndef R6_EULER_WAVES
 #define R6_EULER_WAVES 5   // 90 VGPRs with the register prefetch of the next tile; a budget of 4 waves lets the allocator
@@ -280,36 +246,19 @@ __device__ __forceinline__ void load_tile(const BUF& b, bool has_ep, int64_t e0,
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
-__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(
-#if R6_HOT_ARGS
-        float* const h_state, const float* const h_epconst, const float* const h_action, uint32_t* const h_ep_step, float* const h_ep_return,
-        const int32_t h_n, const int32_t h_ld, const uint32_t share_sweep, const uint32_t n_blocks,
-        const R6Params p, const R6Buffers b, const uint64_t seed, const uint64_t step_index, const uint64_t env_offset) {
-    const HotArgs hot{h_state, h_epconst, h_action, h_ep_step, h_ep_return, h_n, h_ld, share_sweep, n_blocks};
-    const uint32_t even_share_q16 = share_sweep & 0xFFFFu, sweep = share_sweep >> 16;
-    auto load_params = []() __attribute__((always_inline)) { return r6::load_params<kStepParamsOff>(); };
-    auto load_buffers = []() __attribute__((always_inline)) { return r6::load_buffers<kStepParamsOff>(); };
-#else
-        const R6Params p, const R6Buffers b, const uint64_t seed, const uint64_t step_index, const uint64_t env_offset,
-        const uint32_t even_share_q16, const uint32_t sweep) {
-    const R6Buffers& hot = b;
-    const uint32_t n_blocks = gridDim.x;
-    auto load_params = []() __attribute__((always_inline)) { return r6::load_params<0>(); };
-    auto load_buffers = []() __attribute__((always_inline)) { return r6::load_buffers<0>(); };
-#endif
+__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
+                                                      const uint64_t step_index, const uint64_t env_offset,
+                                                      const uint32_t even_share_q16, const uint32_t sweep,
+                                                      uint32_t* const sched, const uint32_t dyn_q) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
     // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
     // reset distribution, the RNG keys) is re-read from the kernarg segment inside those paths
     // (load_params / load_buffers), so that neither occupies SGPRs across the loop.
     __shared__ __attribute__((aligned(16))) float tiles[kWaves][64 * OD];
-    __shared__ float lds_inv_norm_w[kWaves][16];   // every wave keeps its own copy (it fills it behind its own first loads: no wave waits for another one's)
-#if R6_RESET_INLOOP
-    __shared__ int wg_done;       // waves of this workgroup that have left the tile loop (the last one writes the statistics row)
-#else
+    __shared__ float lds_inv_norm[R6_STATE_DIM];
     __shared__ int rq[kResetQueueCap];
     __shared__ int rq_count;
-#endif
     __shared__ int wg_next;
     __shared__ stat_t blk_stats[R6_NUM_STATS];
 
@@ -317,7 +266,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar tile arithmetic
     float* tile = tiles[wave];
-    const int64_t n = hot.n;
+    const int64_t n = b.n;
     const int64_t n_tiles = (n + 63) >> 6;
     // XCD-aware tile split.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 = XCC_ID, checked with
     // s_getreg in the trace build), and the odd XCDs of an MI355X see a ~1 us longer load latency than the even
@@ -326,19 +275,30 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // range is cut into an even-XCD pool of n_tiles * share / 65536 tiles and an odd-XCD pool with the rest, each
     // walked round-robin by the waves of its own workgroups.  0: one pool for everybody.
     // (Round 3 also measured a pool of late-dispatched tail workgroups, a fork/join split of the shard over two streams and
-    // staggered first loads: +-0, +17 us eager and +-0 -- profiles/r3_experiments.json; removed in round 4.)
-    int64_t nw = (int64_t)n_blocks * kWaves;
+    // staggered first loads: +-0, +17 us eager and +-0 -- profiles/r3_experiments.json; removed in round 4.  Round 4 measured,
+    // on one set of buffers (scripts/ab_swap.py; code at commit c9001c0, numbers in profiles/r4_experiments.json): finished envs
+    // re-sampled by their own wave inside the tile loop instead of the dense drain below, +3.4 ... +4.1 us; the draining wave
+    // rotated over the SIMDs, +-0.5; the hot kernel arguments first and preloaded into SGPRs by the command processor
+    // (-amdgpu-kernarg-preload-count), +0.6; a 1024-workgroup grid with exactly four tiles per wave, +2.3; the register
+    // prefetch at four and five waves per SIMD, +3.2 / +5.2.)
+    // Last-round hand-out (experiment, round 4; dyn_q > 0): the last kDynCounters * dyn_q tiles are not on anybody's list.  A wave
+    // that has walked its list pulls them, one at a time and one tile ahead, from the counter of its group of workgroups
+    // (blockIdx % kDynCounters: 40 workgroups of one XCD under round-robin placement; which group serves which tiles never
+    // matters to a result).  Every wave pulls until its counter runs out, so a launch makes exactly dyn_q + (waves of the
+    // group) additions to a counter, and the wave that receives the last possible value puts the counter back to zero.
+    const int64_t n_static = n_tiles - (int64_t)kDynCounters * dyn_q;
+    int64_t nw = (int64_t)gridDim.x * kWaves;
     int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
-    int64_t pool_base = 0, pool_tiles = n_tiles;
+    int64_t pool_base = 0, pool_tiles = n_static;
     if (even_share_q16 != 0u) {
-        const int64_t n_even = (n_tiles * (int64_t)even_share_q16) >> 16;
+        const int64_t n_even = (n_static * (int64_t)even_share_q16) >> 16;
         const bool odd = (blockIdx.x & 1u) != 0u;
         pool_base = odd ? n_even : 0;
-        pool_tiles = odd ? n_tiles - n_even : n_even;
-        nw = (int64_t)(n_blocks >> 1) * kWaves;
+        pool_tiles = odd ? n_static - n_even : n_even;
+        nw = (int64_t)(gridDim.x >> 1) * kWaves;
         t_first = (int64_t)(blockIdx.x >> 1) * kWaves + wave;
     }
-    const bool has_ep = hot.ep_step != nullptr && hot.ep_return != nullptr;
+    const bool has_ep = b.ep_step != nullptr && b.ep_return != nullptr;
     const bool opt_flags_terms = b.flags != nullptr || b.terms != nullptr || b.nfev != nullptr;
 
 #if defined(R6_PHASE_TIMING) || defined(R6_TRACE)   // dev builds: 100 MHz wall-clock stamps instead of the episode statistics
@@ -349,34 +309,24 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     const uint64_t cp_s0 = __builtin_amdgcn_s_memtime();
 #endif
     if (tid == 0) {
-#if R6_RESET_INLOOP
-        wg_done = 0;
-#else
         rq_count = 0;
-#endif
         wg_next = kWaves;   // list entries 0..kWaves-1 are the waves' fixed first tiles
     }
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
+    if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
+        const kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        lds_inv_norm[tid] = ((const __attribute__((address_space(4))) float*)(k + offsetof(R6Params, inv_norm)))[tid];
+    }
     // kEarly (RK4 / RK45 instances): the barrier that publishes the LDS set-up above comes AFTER the wave has requested its
     // first tile (below) -- nothing of the set-up is needed before a tile's reward phase, and the per-lane kernarg read is a
     // memory round trip that the first loads of the launch need not queue behind.
     constexpr bool kEarly = (R6_EARLY_LOAD != 0) && (INTEG != R6_EULER);
-    float* const lds_inv_norm = lds_inv_norm_w[wave];
-    float inv_norm_lane = 0.0f;
-    if (lane < R6_STATE_DIM) {  // per-lane read of the kernarg segment (a cold line: the host wrote it a moment ago): REQUESTED here ...
-        const kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-        inv_norm_lane = ((const __attribute__((address_space(4))) float*)(k + kStepParamsOff + offsetof(R6Params, inv_norm)))[lane];
-    }
-    if constexpr (!kEarly) {
-        __syncthreads();
-        if (lane < R6_STATE_DIM) lds_inv_norm[lane] = inv_norm_lane;
-        wave_lds_sync();
-    }
+    if constexpr (!kEarly) __syncthreads();
 
     // One 64-env tile.  FULL = all 64 lanes are live (every tile but possibly the last one).
     auto process_tile = [&](const int64_t e0, const TileIn& in, auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
-        bool overflow = false;       // R6_RESET_INLOOP: this lane's episode ended (to be re-sampled); else: it did not fit into the reset queue
+        bool overflow = false;       // this lane's finished episode did not fit into the reset queue
         const int64_t rem = n - e0;  // envs from the tile's start to the end of the shard (> 0)
         const bool live = FULL ? true : (lane < rem);
         float y[kDyn];
@@ -507,13 +457,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                 }
                 if (bb.fin_return) bb.fin_return[i] = ep_ret;
                 if (bb.fin_length) bb.fin_length[i] = ep_step;
-#if R6_RESET_INLOOP
-                overflow = true;
-#else
                 const int slot = atomicAdd(&rq_count, 1);
                 if (slot < kResetQueueCap) rq[slot] = (int)i;
                 else overflow = true;   // queue full (mass termination): re-sampled by the tile loop itself
-#endif
             }
         }
 
@@ -544,42 +490,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             }
         }
         wave_lds_sync();  // before the next tile overwrites the LDS tile
-        return (uint64_t)__ballot(overflow);
+        return overflow;
     };
-
-#if R6_RESET_INLOOP
-    // Rocket6DOF.reset (env:180-199) for the envs of tile e0 whose bit is set in `fin` (wave-uniform), by the whole wave: one
-    // Philox pass per env with the four blocks side by side in the lanes (sample_ic_wave: the values of sample_ic, bit for bit),
-    // then the env's lane overwrites its state / epconst / obs / counters.  Called where the wave would otherwise only wait: after
-    // it has requested its NEXT tile (kMinTileLoads loads: `vmcnt_only(kMinTileLoads)` then means "everything older than those
-    // loads is done", i.e. the tile's own stores to the very addresses the reset rewrites -- loads and stores share one in-order
-    // counter on gfx9), or, behind a wave's last tile, after vmcnt(0).  Rounds 1-3 queued these envs per workgroup in LDS and drained
-    // the queue densely after a workgroup barrier at the end of the launch (~1.5 us on the critical path of every workgroup).
-    constexpr int kMinTileLoads = kDyn + 3 + (SHAPING == R6_SHAPING_VELOCITY ? 1 : 0);   // state rows, mass, m0, (v0), action; + 2 when episodes are tracked
-    auto reset_finished = [&](const int64_t e0, uint64_t fin) __attribute__((always_inline)) {
-        const R6Params pp = load_params();
-        const R6Buffers bb = load_buffers();
-        const uint64_t sb = bb.step_base ? *bb.step_base : (uint64_t)0;
-#pragma unroll 1
-        do {
-            const int j = __builtin_ctzll(fin);
-            fin &= fin - 1ull;
-            const int64_t i = e0 + j;
-            float ic[R6_STATE_DIM];
-            sample_ic_wave(pp, seed, env_offset + (uint64_t)i, step_index + sb, lane, ic);
-            if (lane == j) {
-#pragma unroll
-                for (int q = 0; q < R6_STATE_DIM; ++q) bb.state[q * bb.ld + i] = ic[q];
-                bb.epconst[i] = ic[13];
-                bb.epconst[bb.ld + i] = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
-#pragma unroll
-                for (int q = 0; q < OD; ++q) bb.obs[i * OD + q] = ic[q] * pp.inv_norm[q];
-                if (bb.ep_step) bb.ep_step[i] = 0u;
-                if (bb.ep_return) bb.ep_return[i] = 0.0f;
-            }
-        } while (fin != 0ull);
-    };
-#endif
 
     // Tile loop.  (Measured alternatives that did not pay at N = 2^20, where the loop is VALU-bound:
     // register prefetch of the next tile -- +30 VGPRs, one wave per SIMD less, no gain; deferring
@@ -642,10 +554,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     };
     const int n_pos = kWgDyn ? n_wg : n_my;
     int wg_jn = -1;
-#if R6_RESET_INLOOP
-    uint64_t prev_fin = 0ull;   // finished envs of the tile processed last that are still to be re-sampled, and that tile's first env
-    int64_t prev_e0 = 0;
-#endif
     if constexpr (kEarly) {
         // Rotated tile loop: a tile's inputs are requested at the bottom of the previous iteration, the first tile's
         // before the set-up barrier.
@@ -657,64 +565,53 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         int64_t t = 0;
         if (n_pos > 0) {
             t = tile_at(0);
-            if (t < n_full) load_tile<SHAPING, true>(hot, has_ep, t * 64, lane, cur, tile);
-            else load_tile<SHAPING, false>(hot, has_ep, t * 64, lane, cur);
+            if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
+            else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
         }
-        __syncthreads();   // publishes the zeroed counters / statistics above; no wave waits here for memory
-        // ... and consumed here, behind the requests for the wave's first tile and behind the barrier: the wait (for everything this
-        // wave has requested, i.e. for what it needs to start computing anyway) holds up nobody else
-        if (lane < R6_STATE_DIM) lds_inv_norm[lane] = inv_norm_lane;
-        wave_lds_sync();
+        // last-round hand-out: the value a pull returns is consumed one iteration later (a tile ahead: its latency, ~1 us under
+        // load, and the tile's load latency hide behind the tile in progress)
+        const uint32_t ctr = (blockIdx.x & (kDynCounters - 1)) * kDynStride;
+        const uint32_t dyn_waves = (gridDim.x / kDynCounters) * kWaves;
+        bool dyn = dyn_q != 0u && n_pos > 0;
+        uint32_t pull = 0u;
+        if (dyn && n_pos <= 1 && lane == 0) pull = atomicAdd(&sched[ctr], 1u);
+        __syncthreads();
+        bool have = n_pos > 0;
 #pragma unroll 1
-        for (int pos = 0; pos < n_pos;) {
+        for (int pos = 0; have;) {
             if (sweep & 4u) {   // A/B: no priority ladder (oldest wave first)
             } else if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
             else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
             else if (tile_no == 2) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
             ++tile_no;
-            uint64_t overflow;
+            bool overflow;
             if (t < n_full) overflow = process_tile(t * 64, cur, std::true_type{});
             else overflow = process_tile(t * 64, cur, std::false_type{});
-#if R6_RESET_INLOOP == 2
-            // one tile later: the envs that finished in the tile BEFORE this one -- their tile's stores are older than this tile's
-            // loads, which process_tile has consumed, so nothing has to be waited for
-            const int64_t t_done = t;
-            ++pos;
-            if (pos < n_pos) {
-                t = tile_at(pos);
-                if (t < n_full) load_tile<SHAPING, true>(hot, has_ep, t * 64, lane, cur, tile);
-                else load_tile<SHAPING, false>(hot, has_ep, t * 64, lane, cur);
-            }
-            if (__builtin_expect(prev_fin != 0ull, 0)) reset_finished(prev_e0, prev_fin);
-            prev_fin = overflow;
-            prev_e0 = t_done * 64;
-#elif R6_RESET_INLOOP
-            const int64_t t_done = t;
-            ++pos;
-            if (pos < n_pos) {
-                t = tile_at(pos);
-                if (t < n_full) load_tile<SHAPING, true>(hot, has_ep, t * 64, lane, cur, tile);
-                else load_tile<SHAPING, false>(hot, has_ep, t * 64, lane, cur);
-            }
-            if (__builtin_expect(overflow != 0ull, 0)) {
-                // the next tile is on its way: re-sample the envs that just finished, behind their own tile's stores
-                if (pos < n_pos && t < n_full) __builtin_amdgcn_s_waitcnt(vmcnt_only(kMinTileLoads));
-                else __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
-                reset_finished(t_done * 64, overflow);
-            }
-#else
-            if (__builtin_expect(overflow != 0ull, 0)) {
+            if (__builtin_expect(__any(overflow), 0)) {
                 __builtin_amdgcn_s_waitcnt(0);
-                if ((overflow >> lane) & 1ull) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
+                if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
             }
             ++pos;
             if (pos < n_pos) {
                 t = tile_at(pos);
-                if (t < n_full) load_tile<SHAPING, true>(hot, has_ep, t * 64, lane, cur, tile);
-                else load_tile<SHAPING, false>(hot, has_ep, t * 64, lane, cur);
+            } else if (dyn) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)pull);
+                if (v < dyn_q) {
+                    t = n_static + (int64_t)(blockIdx.x & (kDynCounters - 1)) * dyn_q + v;
+                } else {
+                    have = false;
+                    dyn = false;
+                    if (v == dyn_q + dyn_waves - 1u && lane == 0) __hip_atomic_store(&sched[ctr], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                have = false;
             }
-#endif
+            if (have) {
+                if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
+                else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
+                if (dyn && pos + 1 >= n_pos && lane == 0) pull = atomicAdd(&sched[ctr], 1u);   // for the tile after the one just requested
+            }
         }
     } else {
 #pragma unroll 1
@@ -729,7 +626,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         else __builtin_amdgcn_s_setprio(0);
         ++tile_no;
         TileIn cur;
-        uint64_t overflow;
+        bool overflow;
 #ifdef R6_TRACE   // dev build (scripts/trace_timeline.py): per wave and tile, 100 MHz stamps around the load / compute / store phases
         uint32_t* trc = reinterpret_cast<uint32_t*>(b.stats) + ((int64_t)blockIdx.x * kWaves + wave) * 24;
         const uint32_t tr_a = (uint32_t)wall_clock64();
@@ -740,7 +637,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                 // requested into registers (18 more, which the 4-waves-per-SIMD budget of this instance has)
                 // before this tile is computed: 37.0 -> 34.7 us.  The same costs the RK4 instance 1.2 us.
                 if (have_nxt) cur = nxt;
-                else load_tile<SHAPING, true>(hot, has_ep, t * 64, lane, cur);
+                else load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur);
                 int pos_n = pos + 1;
                 if constexpr (kWgDyn) {   // the tile after this one is claimed now, so that its inputs can be requested
                     int nj = 0;
@@ -751,17 +648,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                 const int64_t tsn = pool_base + list_tile(pos_n < n_pos ? pos_n : pos);
                 const int64_t tn = (sweep & 2u) ? (n_tiles - 1 - tsn) : tsn;
                 have_nxt = pos_n < n_pos && tn < n_full;
-                if (have_nxt) load_tile<SHAPING, true>(hot, has_ep, tn * 64, lane, nxt);
-#if R6_RESET_INLOOP == 1
-                if (__builtin_expect(prev_fin != 0ull, 0)) {   // the previous tile's finished envs, behind that tile's stores (see reset_finished)
-                    if (have_nxt) __builtin_amdgcn_s_waitcnt(vmcnt_only(kMinTileLoads));
-                    else __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
-                    reset_finished(prev_e0, prev_fin);
-                    prev_fin = 0ull;
-                }
-#endif
+                if (have_nxt) load_tile<SHAPING, true>(b, has_ep, tn * 64, lane, nxt);
             } else {
-                load_tile<SHAPING, true>(hot, has_ep, t * 64, lane, cur, tile);
+                load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
             }
 #ifdef R6_TRACE
             __builtin_amdgcn_s_waitcnt(0);
@@ -787,24 +676,15 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
 #endif
         } else {
             have_nxt = false;
-            load_tile<SHAPING, false>(hot, has_ep, t * 64, lane, cur);
+            load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
             overflow = process_tile(t * 64, cur, std::false_type{});
         }
-#if R6_RESET_INLOOP
-        if (__builtin_expect(prev_fin != 0ull, 0)) {   // mode 1: not taken up by a prefetching iteration (no prefetch: RK4 instances with R6_EARLY_LOAD=0; partial tile)
-            if (R6_RESET_INLOOP == 1) __builtin_amdgcn_s_waitcnt(vmcnt_only(0));   // mode 2: the tile before this one -- its stores are older than this tile's consumed loads
-            reset_finished(prev_e0, prev_fin);
-        }
-        prev_fin = overflow;
-        prev_e0 = t * 64;
-#else
-        if (__builtin_expect(overflow != 0ull, 0)) {
+        if (__builtin_expect(__any(overflow), 0)) {
             // Reset queue full (mass termination, e.g. the first landing wave of envs started in lockstep):
             // these lanes re-sample their env right here, once the tile's terminal outputs have left the wave.
             __builtin_amdgcn_s_waitcnt(0);
-            if ((overflow >> lane) & 1ull) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
+            if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
         }
-#endif
         if constexpr (kWgDyn) {
             if (wg_jn >= 0) {   // claimed ahead by the prefetch
                 pos = wg_jn;
@@ -819,28 +699,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         }
     }
     }   // !kEarly
-#if R6_RESET_INLOOP
-    if (prev_fin != 0ull) {   // the last tile's finished envs
-        __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
-        reset_finished(prev_e0, prev_fin);
-    }
-#endif
     __builtin_amdgcn_s_setprio(0);
 
-#if R6_RESET_INLOOP
-    // No workgroup barrier and no drain: a wave that has walked its tiles (and re-sampled its own finished envs) is done.  The
-    // statistics of the workgroup leave with the wave that arrives last (LDS operations of a wave complete in order: when the
-    // counter reads kWaves - 1, every other wave's additions to blk_stats have been made).
-#if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE) && !defined(R6_CLOCK_PROBE)
-    if (b.stats) {
-        int arrived = 0;
-        if (lane == 0) arrived = atomicAdd(&wg_done, 1);
-        arrived = __builtin_amdgcn_readfirstlane(arrived);
-        if (arrived == kWaves - 1 && lane < R6_NUM_STATS && blk_stats[R6_STAT_EPISODES] != 0ull)
-            b.stats[(int64_t)blockIdx.x * R6_NUM_STATS + lane] += stats_value(blk_stats, lane);
-    }
-#endif
-#else
 #ifdef R6_PHASE_TIMING
     const uint64_t pt1 = wall_clock64();
 #endif
@@ -863,14 +723,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
         const R6Params pp = load_params();
         const int n_rec = n_queued < kResetQueueCap ? n_queued : kResetQueueCap;   // the rest was handled in the loop
-#ifndef R6_DRAIN_ROTATE
-#define R6_DRAIN_ROTATE 0
-#endif
-        // R6_DRAIN_ROTATE: the few queued envs (about four per workgroup and step) are one pass of ONE wave; left at wave 0 that is
-        // SIMD 0 of the CU for each of its five workgroups.  Workgroups b, b + 256, b + 512 ... share a CU (dealt round-robin over
-        // 8 XCDs x 32 CUs): the draining wave follows (b / 256) % 4, so the passes spread over the four SIMDs.
-        const int rot = R6_DRAIN_ROTATE ? (int)((blockIdx.x >> 8) & 3u) * 64 : 0;
-        for (int k = (tid + kBlock - rot) & (kBlock - 1); k < n_rec; k += kBlock)
+        for (int k = tid; k < n_rec; k += kBlock)
             reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
     } else if (!p.auto_reset) {
         const R6Buffers bb = load_buffers();
@@ -879,7 +732,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             bb.stats[(int64_t)blockIdx.x * R6_NUM_STATS + tid] += stats_value(blk_stats, tid);
 #endif
     }
-#endif   // R6_RESET_INLOOP
 #ifdef R6_CLOCK_PROBE
     if (b.stats && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1678,7 +1530,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 int validate_common(const R6Params* p, const R6Buffers* b) {
     if (!p || !b) return fail(R6_E_BADARG, "null params/buffers");
     if (b->n < 0 || b->ld < b->n) return fail(R6_E_BADARG, "need 0 <= n <= ld");
-    if (b->n >= (int64_t)1 << 31 || b->ld >= (int64_t)1 << 31) return fail(R6_E_BADARG, "n and ld must be < 2^31 per shard");
+    if (b->n >= (int64_t)1 << 31) return fail(R6_E_BADARG, "n must be < 2^31 per shard");
     if (p->obs_dim != 13 && p->obs_dim != 14) return fail(R6_E_BADARG, "obs_dim must be 13 or 14");
     if (p->integrator != R6_EULER && p->integrator != R6_RK4 && p->integrator != R6_RK45) return fail(R6_E_BADARG, "bad integrator");
     if (p->n_substeps < 1 || p->n_substeps > 4096) return fail(R6_E_BADARG, "n_substeps out of range");
@@ -1744,6 +1596,7 @@ struct StepTune {
     std::atomic<int> grid_blocks{0};                         // > 0: pins the persistent grid (R6_GRID_BLOCKS)
     std::atomic<int> sweep{R6_SWEEP_DEFAULT};
     std::atomic<int> sweep_flags{0};                         // A/B bit passed to the kernel: 4 = no priority ladder
+    std::atomic<double> dyn_frac{0.0};                       // experiment: share of the tiles handed out from counters in the last round
     std::atomic<int> balanced_tpw{2};                        // tiles per wave of the dispatcher-balanced grid (large shards)
     std::atomic<int> nt_mode{-1};                            // -1: streaming stores by shard size (default), 0: never, 1: always
     StepTune() {
@@ -1761,8 +1614,31 @@ uint32_t even_xcd_share_q16(int integrator) {
     const double forced = tune().even_share.load(std::memory_order_relaxed);
     const double f = forced >= 0.0 ? forced : (integrator == R6_EULER ? 0.56 : 0.54);
     if (!(f > 0.0) || f == 0.5 || f >= 1.0) return 0u;
-    const uint32_t q = (uint32_t)(f * 65536.0 + 0.5);
-    return q > 65535u ? 65535u : q;   // travels in 16 bits of a kernel argument
+    return (uint32_t)(f * 65536.0 + 0.5);
+}
+
+// Counters of the last-round hand-out (experiment): one device buffer per process, zero between launches (the kernel puts every
+// counter back), allocated at the first launch outside a stream capture.  One stepping stream at a time.
+static uint32_t* sched_counters(hipStream_t s) {
+    static std::atomic<uint32_t*> buf{nullptr};
+    uint32_t* d = buf.load(std::memory_order_acquire);
+    if (d) return d;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    d = buf.load(std::memory_order_acquire);
+    if (d) return d;
+    const size_t bytes = sizeof(uint32_t) * r6::kDynCounters * r6::kDynStride;
+    if (hipMalloc(reinterpret_cast<void**>(&d), bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    buf.store(d, std::memory_order_release);
+    return d;
 }
 
 // One launch of the step kernel over a whole shard.
@@ -1773,7 +1649,11 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
         // ONE: n_substeps == 1 (the reference's configuration) gets the straight-line integrator instance;
         // NT: non-temporal output stores for working sets far beyond the Infinity Cache
         const int nt_mode = tune().nt_mode.load(std::memory_order_relaxed);
-        const bool nt = nt_mode >= 0 ? nt_mode != 0 : b.n >= R6_NT_MIN_ENVS;
+        // ... and for the window in which the rows the next step re-reads (state, m0: 128 B per env with the action) fit the
+        // 256 MB Infinity Cache only if the outputs do not pass through it: measured on one set of buffers (round 4,
+        // profiles/r4_experiments.json; plain | streaming stores, us per step): 1.31 M envs 44.5 | 42.9, 1.57 M 59.9 | 51.2,
+        // 1.84 M 76.1 | 61.1, 2^21 81.2 | 73.0 -- and 2.62 M 98.9 | 106.6, 3.15 M 110.6 | 113.8, 2^22 146.1 | 148.7, 5.2 M and up equal.
+        const bool nt = nt_mode >= 0 ? nt_mode != 0 : (b.n >= R6_NT_MIN_ENVS || (b.n >= R6_NT_WINDOW_LO && b.n < R6_NT_WINDOW_HI));
         if (p.n_substeps == 1) kernel = nt ? r6::step_kernel<INTEG, SHAPING, OD, true, true> : r6::step_kernel<INTEG, SHAPING, OD, false, true>;
         else if (nt) kernel = r6::step_kernel<INTEG, SHAPING, OD, true, false>;
     }
@@ -1812,12 +1692,16 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     uint32_t sweep = 0;
     if (step & 1) sweep = (blocks > cap || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
     sweep |= (uint32_t)tune().sweep_flags.load(std::memory_order_relaxed) & 4u;
-#if R6_HOT_ARGS
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, b.state, (const float*)b.epconst, b.action, b.ep_step, b.ep_return,
-                       (int32_t)b.n, (int32_t)b.ld, (even_share & 0xFFFFu) | (sweep << 16), (uint32_t)blocks, p, b, seed, step, off);
-#else
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep);
-#endif
+    // last-round hand-out (experiment): a share of the tiles is pulled from counters instead of standing on a wave's list
+    uint32_t dyn_q = 0;
+    uint32_t* sched = nullptr;
+    const double dyn_frac = tune().dyn_frac.load(std::memory_order_relaxed);
+    if (dyn_frac > 0.0 && dyn_frac < 0.5 && persistent && INTEG != R6_EULER && (blocks % r6::kDynCounters) == 0 && (sweep & 3u) == 0u) {
+        const int64_t q = (int64_t)((double)n_tiles * dyn_frac / r6::kDynCounters);
+        // every wave keeps at least one listed tile in either XCD pool
+        if (q > 0 && (n_tiles - q * r6::kDynCounters) * 45 / 100 >= blocks / 2 * r6::kWaves && (sched = sched_counters(s)) != nullptr) dyn_q = (uint32_t)q;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep, sched, dyn_q);
 }
 
 // The device error word: step_k_pair_kernel raises it when one of its bounded waits ran out.  Mapped host memory, allocated by the
@@ -1968,6 +1852,7 @@ int r6_tune(const char* key, double value) {
     else if (!std::strcmp(key, "grid_blocks")) t.grid_blocks = (int)value;
     else if (!std::strcmp(key, "sweep")) t.sweep = (int)value;
     else if (!std::strcmp(key, "sweep_flags")) t.sweep_flags = (int)value;
+    else if (!std::strcmp(key, "dyn_tail_frac")) t.dyn_frac = value;
     else if (!std::strcmp(key, "balanced_tiles_per_wave")) t.balanced_tpw = (int)value;
     else if (!std::strcmp(key, "streaming_stores")) t.nt_mode = (int)value;
     else return fail(R6_E_BADARG, "r6_tune: unknown key");

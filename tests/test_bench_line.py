@@ -172,16 +172,23 @@ def test_two_rank_line_over_gloo():
 
 
 def test_valu_object_from_the_committed_profile():
-    """bench.py's `valu` object (the step kernel's second limiter): derived from profiles/r3_pmc_valu.json and the run's
-    kernel time, only for the profiled workload, and labelled as a static file."""
+    """bench.py's `valu` object (the step kernel's second resource): the launch's vector instructions (committed PMC pass of the
+    workload) priced at the MEASURED issue rates -- 1.2 / 1.8 / 3.4 ns, not the quad-cycle the SQ counters tick in (round-3 review,
+    item 4) -- only for the profiled workload, and labelled as a static file."""
     import bench
 
-    v = bench.valu_from_profile("raw", "rk4", 1 << 20, 1, 0.0375)
-    assert v is not None and 0.5 < v["busy_frac"] < 1.0 and "static file" in v["source"]
+    t = bench.valu_issue_time_us(15.57e6, 0.81e6)
+    assert 18.0 < t["floor_us"] < 18.5 and t["floor_us"] < t["priced_us"] < 22.0        # 950 instructions x 16 tiles per SIMD
+    v = bench.valu_from_profile("raw", "rk4", 1 << 20, 1, 0.0367)
+    assert v is not None and 0.45 < v["share_of_launch"] < 0.70 and "static file" in v["source"]
+    assert v["issue_time_floor_us_per_simd"] < v["issue_time_us_per_simd"] < 25.0
     assert 900 < v["instructions_per_64_env_tile"] < 1000
+    assert "busy_frac" not in v, "the 4-cycles-per-instruction figure is gone from the line"
     assert bench.valu_from_profile("raw", "euler", 1 << 20, 1, 0.0375) is None
     assert bench.valu_from_profile("raw", "rk4", 1 << 16, 1, 0.0375) is None
     assert bench.valu_from_profile("raw", "rk4", 1 << 20, 16, 0.0375) is None
+    b = bench.small_batch_bound(65536, "euler", 0.04, 16, 38e-6)
+    assert b["bound"] == "dependent_chain_of_one_tile_per_simd" and 0.1 < b["frac"] < 0.6 and "share_of_wave_cycles" in b
 
 
 def test_rollout_gather_loop_is_warmed_and_itemised(monkeypatch):

@@ -119,14 +119,14 @@ def test_determinism_and_sharding_invariance(torch_cuda, cfg):
     assert torch.equal(full.done[N // 2:], hi.done)
 
 
-def test_streaming_store_form_matches_the_plain_form(torch_cuda, cfg):
-    """From 3 * 2^21 envs on the launcher picks the kernel form whose obs / reward / done stores carry the
-    non-temporal hint (r6_kernels.hip, stream_store).  One batch of that size against its two half-size shards
-    (plain form, global env indices via env_offset): every output bit for bit, resets included."""
+@pytest.mark.parametrize("n", [3 << 21, 1 << 21])
+def test_streaming_store_form_matches_the_plain_form(torch_cuda, cfg, n):
+    """From 3 * 2^21 envs on, and (round 4) between 1.2 M and 2.36 M envs, the launcher picks the kernel form whose obs / reward /
+    done stores carry the non-temporal hint (r6_kernels.hip, stream_store).  One batch of such a size against its two half-size
+    shards (plain form: 3 * 2^20 resp. 2^20 envs; global env indices via env_offset): every output bit for bit, resets included."""
     torch = torch_cuda
     from rl_rocket_6dof_amd import BatchedRocket6DOF
 
-    n = 3 << 21
     h = n // 2
     for integ, dt in (("rk4", 0.1), ("euler", 0.04)):
         big = BatchedRocket6DOF(n, cfg, integrator=integ, timestep=dt, seed=9)
