@@ -162,8 +162,10 @@ int r6_clear_device_error(void);
 
 /* Launch-shape knobs of r6_step (process-wide; results never depend on them, only which wave computes which tile).  Keys:
  * "even_xcd_share" (share of the tiles given to the workgroups on even XCDs, < 0 = default), "grid_blocks" (> 0 pins the
- * persistent grid), "sweep" (tile order on odd steps, -1 = default), "sweep_flags" (4: no wave-priority ladder).  The first three
- * are also read once from the environment: R6_EVEN_XCD_SHARE, R6_GRID_BLOCKS, R6_SWEEP. */
+ * persistent grid), "sweep" (tile order on odd steps, -1 = default), "sweep_flags" (4: no wave-priority ladder),
+ * "balanced_tiles_per_wave" (large shards: tiles per wave of the dispatcher-balanced grid, 0 = by shard size), "streaming_stores"
+ * (non-temporal output stores: -1 = by shard size, 0 = never, 1 = always).  The first three are also read once from the environment:
+ * R6_EVEN_XCD_SHARE, R6_GRID_BLOCKS, R6_SWEEP. */
 int r6_tune(const char *key, double value);
 
 /* Rocket6DOF.step for n envs (rocket_env.py:201-231): denormalise action, integrate one env

@@ -66,7 +66,6 @@ constexpr int kWaves = kBlock / 64;
 #define R6_EARLY_LOAD 1         // A/B switch (RK4 / RK45 instances): rotated tile loop, first tile requested before the set-up barrier
 #endif
 constexpr int kResetQueueCap = R6_RESET_QUEUE;
-constexpr int kDynCounters = 32, kDynStride = 32;   // last-round hand-out: counters, and dwords between two of them (128 B: a line each)
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS instructions of one wave execute in order; this only stops the compiler from moving
@@ -248,8 +247,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
 __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset,
-                                                      const uint32_t even_share_q16, const uint32_t sweep,
-                                                      uint32_t* const sched, const uint32_t dyn_q) {
+                                                      const uint32_t even_share_q16, const uint32_t sweep) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
     // compiler).  Everything that is needed once per tile as a per-lane value (the 14 normaliser
     // reciprocals) sits in LDS, and everything that only rare paths need (terminal outputs, the
@@ -280,21 +278,17 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // re-sampled by their own wave inside the tile loop instead of the dense drain below, +3.4 ... +4.1 us; the draining wave
     // rotated over the SIMDs, +-0.5; the hot kernel arguments first and preloaded into SGPRs by the command processor
     // (-amdgpu-kernarg-preload-count), +0.6; a 1024-workgroup grid with exactly four tiles per wave, +2.3; the register
-    // prefetch at four and five waves per SIMD, +3.2 / +5.2.)
-    // Last-round hand-out (experiment, round 4; dyn_q > 0): the last kDynCounters * dyn_q tiles are not on anybody's list.  A wave
-    // that has walked its list pulls them, one at a time and one tile ahead, from the counter of its group of workgroups
-    // (blockIdx % kDynCounters: 40 workgroups of one XCD under round-robin placement; which group serves which tiles never
-    // matters to a result).  Every wave pulls until its counter runs out, so a launch makes exactly dyn_q + (waves of the
-    // group) additions to a counter, and the wave that receives the last possible value puts the counter back to zero.
-    const int64_t n_static = n_tiles - (int64_t)kDynCounters * dyn_q;
+    // prefetch at four and five waves per SIMD, +3.2 / +5.2; the last 3-20 % of the tiles handed out in the final round from 32
+    // self-resetting counters, claimed a tile ahead, -0.1 ... +0.6 (code at commit d51f2ad).  None moved the launch by the
+    // 1 us the review's stop rule asks for: DESIGN.md section 4.)
     int64_t nw = (int64_t)gridDim.x * kWaves;
     int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
-    int64_t pool_base = 0, pool_tiles = n_static;
+    int64_t pool_base = 0, pool_tiles = n_tiles;
     if (even_share_q16 != 0u) {
-        const int64_t n_even = (n_static * (int64_t)even_share_q16) >> 16;
+        const int64_t n_even = (n_tiles * (int64_t)even_share_q16) >> 16;
         const bool odd = (blockIdx.x & 1u) != 0u;
         pool_base = odd ? n_even : 0;
-        pool_tiles = odd ? n_static - n_even : n_even;
+        pool_tiles = odd ? n_tiles - n_even : n_even;
         nw = (int64_t)(gridDim.x >> 1) * kWaves;
         t_first = (int64_t)(blockIdx.x >> 1) * kWaves + wave;
     }
@@ -568,17 +562,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
             else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
         }
-        // last-round hand-out: the value a pull returns is consumed one iteration later (a tile ahead: its latency, ~1 us under
-        // load, and the tile's load latency hide behind the tile in progress)
-        const uint32_t ctr = (blockIdx.x & (kDynCounters - 1)) * kDynStride;
-        const uint32_t dyn_waves = (gridDim.x / kDynCounters) * kWaves;
-        bool dyn = dyn_q != 0u && n_pos > 0;
-        uint32_t pull = 0u;
-        if (dyn && n_pos <= 1 && lane == 0) pull = atomicAdd(&sched[ctr], 1u);
         __syncthreads();
-        bool have = n_pos > 0;
 #pragma unroll 1
-        for (int pos = 0; have;) {
+        for (int pos = 0; pos < n_pos;) {
             if (sweep & 4u) {   // A/B: no priority ladder (oldest wave first)
             } else if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
             else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
@@ -595,22 +581,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             ++pos;
             if (pos < n_pos) {
                 t = tile_at(pos);
-            } else if (dyn) {
-                const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)pull);
-                if (v < dyn_q) {
-                    t = n_static + (int64_t)(blockIdx.x & (kDynCounters - 1)) * dyn_q + v;
-                } else {
-                    have = false;
-                    dyn = false;
-                    if (v == dyn_q + dyn_waves - 1u && lane == 0) __hip_atomic_store(&sched[ctr], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            } else {
-                have = false;
-            }
-            if (have) {
                 if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
                 else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
-                if (dyn && pos + 1 >= n_pos && lane == 0) pull = atomicAdd(&sched[ctr], 1u);   // for the tile after the one just requested
             }
         }
     } else {
@@ -1596,8 +1568,7 @@ struct StepTune {
     std::atomic<int> grid_blocks{0};                         // > 0: pins the persistent grid (R6_GRID_BLOCKS)
     std::atomic<int> sweep{R6_SWEEP_DEFAULT};
     std::atomic<int> sweep_flags{0};                         // A/B bit passed to the kernel: 4 = no priority ladder
-    std::atomic<double> dyn_frac{0.0};                       // experiment: share of the tiles handed out from counters in the last round
-    std::atomic<int> balanced_tpw{2};                        // tiles per wave of the dispatcher-balanced grid (large shards)
+    std::atomic<int> balanced_tpw{0};                        // tiles per wave of the dispatcher-balanced grid (large shards); 0 = by shard size
     std::atomic<int> nt_mode{-1};                            // -1: streaming stores by shard size (default), 0: never, 1: always
     StepTune() {
         if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) even_share = std::atof(e);
@@ -1615,30 +1586,6 @@ uint32_t even_xcd_share_q16(int integrator) {
     const double f = forced >= 0.0 ? forced : (integrator == R6_EULER ? 0.56 : 0.54);
     if (!(f > 0.0) || f == 0.5 || f >= 1.0) return 0u;
     return (uint32_t)(f * 65536.0 + 0.5);
-}
-
-// Counters of the last-round hand-out (experiment): one device buffer per process, zero between launches (the kernel puts every
-// counter back), allocated at the first launch outside a stream capture.  One stepping stream at a time.
-static uint32_t* sched_counters(hipStream_t s) {
-    static std::atomic<uint32_t*> buf{nullptr};
-    uint32_t* d = buf.load(std::memory_order_acquire);
-    if (d) return d;
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    d = buf.load(std::memory_order_acquire);
-    if (d) return d;
-    const size_t bytes = sizeof(uint32_t) * r6::kDynCounters * r6::kDynStride;
-    if (hipMalloc(reinterpret_cast<void**>(&d), bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    buf.store(d, std::memory_order_release);
-    return d;
 }
 
 // One launch of the step kernel over a whole shard.
@@ -1670,8 +1617,11 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
         // hardware dispatcher balances better than a fixed tile list per wave: two tiles per wave, as many
         // workgroups as the per-workgroup statistics rows allow (N = 2^22: 4.6 -> 5.1 TB/s algorithmic, 2^23:
         // 3.8 -> 4.6, 2^24: 3.8 -> 5.1; at 2^20 / 2^21 the resident grid is 4-13 % faster).
+        // two tiles per wave; four from 6.3 M envs on (round 4, one set of buffers, tiles per wave 2 | 3 | 4 | 5 | 8, us per step:
+        // 2^22 envs 156.7 | 157.2 | 165.1 | 162.9 | 176.7; 6.3 M 228.5 | 230.1 | 229.0 | 233.6 | 236.1; 2^23 298.3 | 297.8 | 292.2 |
+        // 303.8 | 309.6 (three sessions: -3.8, -9.4, -6.1 us for four); 12.6 M 472.8 | 473.6 | 474.2 | 485.9 | 493.6)
         int tpw = tune().balanced_tpw.load(std::memory_order_relaxed);
-        if (tpw < 1) tpw = 1;
+        if (tpw < 1) tpw = b.n >= R6_NT_MIN_ENVS ? 4 : 2;
         const int64_t big = n_tiles / (tpw * r6::kWaves);
         balanced = pinned_blocks <= 0 && n_tiles >= 49152 && big > cap;
         blocks = balanced ? (big < R6_MAX_BLOCKS ? big : R6_MAX_BLOCKS) : cap;
@@ -1692,16 +1642,7 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     uint32_t sweep = 0;
     if (step & 1) sweep = (blocks > cap || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
     sweep |= (uint32_t)tune().sweep_flags.load(std::memory_order_relaxed) & 4u;
-    // last-round hand-out (experiment): a share of the tiles is pulled from counters instead of standing on a wave's list
-    uint32_t dyn_q = 0;
-    uint32_t* sched = nullptr;
-    const double dyn_frac = tune().dyn_frac.load(std::memory_order_relaxed);
-    if (dyn_frac > 0.0 && dyn_frac < 0.5 && persistent && INTEG != R6_EULER && (blocks % r6::kDynCounters) == 0 && (sweep & 3u) == 0u) {
-        const int64_t q = (int64_t)((double)n_tiles * dyn_frac / r6::kDynCounters);
-        // every wave keeps at least one listed tile in either XCD pool
-        if (q > 0 && (n_tiles - q * r6::kDynCounters) * 45 / 100 >= blocks / 2 * r6::kWaves && (sched = sched_counters(s)) != nullptr) dyn_q = (uint32_t)q;
-    }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep, sched, dyn_q);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep);
 }
 
 // The device error word: step_k_pair_kernel raises it when one of its bounded waits ran out.  Mapped host memory, allocated by the
@@ -1852,7 +1793,6 @@ int r6_tune(const char* key, double value) {
     else if (!std::strcmp(key, "grid_blocks")) t.grid_blocks = (int)value;
     else if (!std::strcmp(key, "sweep")) t.sweep = (int)value;
     else if (!std::strcmp(key, "sweep_flags")) t.sweep_flags = (int)value;
-    else if (!std::strcmp(key, "dyn_tail_frac")) t.dyn_frac = value;
     else if (!std::strcmp(key, "balanced_tiles_per_wave")) t.balanced_tpw = (int)value;
     else if (!std::strcmp(key, "streaming_stores")) t.nt_mode = (int)value;
     else return fail(R6_E_BADARG, "r6_tune: unknown key");

@@ -24,8 +24,8 @@ cfg = default_env_config()
 dev = torch.device("cuda:0")
 n = args.n
 libs = dict(x.split("=") for x in args.libs.split(",")) if args.libs else {"": None}
-KEYS = {"even": "even_xcd_share", "grid": "grid_blocks", "sweep": "sweep", "flags": "sweep_flags", "dyn": "dyn_tail_frac", "nt": "streaming_stores", "tpw": "balanced_tiles_per_wave"}
-DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0, "dyn_tail_frac": 0.0, "streaming_stores": -1, "balanced_tiles_per_wave": 2}
+KEYS = {"even": "even_xcd_share", "grid": "grid_blocks", "sweep": "sweep", "flags": "sweep_flags", "nt": "streaming_stores", "tpw": "balanced_tiles_per_wave"}
+DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0, "streaming_stores": -1, "balanced_tiles_per_wave": 0}
 
 
 def apply(shape, lib):

@@ -16,8 +16,9 @@ SHAPES = [
     {"grid_blocks": 768, "sweep": 2},
     {"sweep": 1},
     {"sweep_flags": 4},                                        # no priority ladder
+    {"streaming_stores": 1},                                   # non-temporal output stores (the launcher's choice from 1.2 M envs on)
 ]
-DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0}
+DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0, "streaming_stores": -1, "balanced_tiles_per_wave": 0}
 
 
 def _run(torch, shape, wrapped, steps, n, graph=False):
@@ -80,6 +81,19 @@ def test_default_launch_records_into_a_graph():
     got = _run(torch, {"even_xcd_share": 0.5}, False, 2, n, graph=True)
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), f"output {i}"
+
+
+def test_balanced_grid_shapes_are_bit_identical():
+    """From 49 152 tiles (3.1 M envs) on the grid is dispatcher-balanced (a few tiles per wave, the tile range mirrored on odd
+    steps): tiles per wave and the store form never change a result."""
+    import torch
+
+    n = 49152 * 64
+    ref = _run(torch, {}, False, 40, n)
+    for shape in ({"balanced_tiles_per_wave": 1}, {"balanced_tiles_per_wave": 4}, {"balanced_tiles_per_wave": 3, "streaming_stores": 1}):
+        got = _run(torch, shape, False, 40, n)
+        for i, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), f"shape {shape}: output {i} differs from the default launch"
 
 
 def test_small_shards_ignore_the_knobs():
