@@ -20,6 +20,7 @@ Beside the headline the same line carries (N = 1 only, all timed in this run):
                   Infinity Cache that holds the whole headline working set (198 MB);
   `configs1`      BASELINE configs[1] -- 65 536 envs, Euler dt 0.04 -- one launch per step and 16 steps per launch
                   (r6_step_k), each with its own algorithmic-bytes figure;
+  `rk45`          the headline size stepped by the in-kernel adaptive RK45 twin of the reference's integrator;
   `cpu_baseline`  the reference-equivalent CPU restatement (oracle/, scalar Python: adaptive RK45 + ground event +
                   np.roots reward, the same algorithm and structure as the reference's Rocket6DOF.step) on this box.
 With N > 1 the line carries `rccl`: the process-group facts (backend, ranks), per-rank kernel times, and a second short
@@ -747,6 +748,10 @@ def main(argv=None):
                     torch, dev, cfg, n=65536, integrator="euler", dt=0.04, k=16, pool_count=2, burnin=2000, steps=8000,
                     warmup=800, label="BASELINE configs[1]: 65 536 envs, Euler dt 0.04, r6_step_k with 16 steps per launch, "
                                       "all per-step outputs stored")}
+            extras["rk45"] = side_measurement(
+                torch, dev, cfg, n=1 << 20, integrator="rk45", dt=None, k=1, pool_count=2, burnin=600, steps=200, warmup=40,
+                label="2^20 envs, in-kernel adaptive RK45 (scipy's step control, the reference's own integrator: simulator.py:83-88), dt 0.1, raw step: "
+                      "bound by arithmetic (8-20 RHS evaluations per env step, the wave follows its slowest lane), not by HBM")
             extras["ppo_training"] = ppo_side_measurement(torch, dev)
         if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:
             extras["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // (j / kWaves) * nw + first tile of the workgroup + (j % kWaves).  Measured at N = 2^20: Euler 35.1 -> 34.0 us;
     // the RK4 instances lose with it (38.1 -> 38.7 claimed ahead, 40.0 claimed late: a wave that takes a tile late
     // in the launch finishes it alone) and keep their fixed per-wave lists.
-    constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;
+    constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;   // (the adaptive instances with it: 108.8 -> 122.8 us, round 4)
     const int64_t wg_first = t_first - wave;
     // Order of a wave's (workgroup's) tile list, chosen per launch by the host (launch_step_inst has the numbers).
     // sweep bit 0: the list is walked backwards -- the tile a wave wrote last in the previous launch is the one it reads
@@ -1414,6 +1414,18 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     if (tid == 0 && host_abort && abort_word != 0) __hip_atomic_store(host_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+#ifdef R6_TEST_HOOKS
+__global__ __launch_bounds__(kPairBlock, 1) void wave_placement_kernel(uint32_t* out) {
+    __shared__ float pad[kPairTiles][kRing][kSlotWords][64];   // the pair kernel's LDS footprint: one workgroup per CU, as there
+    if (threadIdx.x == 0) pad[0][0][0][0] = 0.0f;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        out[((int64_t)blockIdx.x * (kPairBlock / 64) + wave) * 2 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        out[((int64_t)blockIdx.x * (kPairBlock / 64) + wave) * 2 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+}
+#endif
+
 // -------------------------------------------------------------------------------------------------
 // Rocket6DOF.reset (env:180-199) for masked envs.
 // -------------------------------------------------------------------------------------------------
@@ -1583,7 +1595,8 @@ StepTune& tune() {
 
 uint32_t even_xcd_share_q16(int integrator) {
     const double forced = tune().even_share.load(std::memory_order_relaxed);
-    const double f = forced >= 0.0 ? forced : (integrator == R6_EULER ? 0.56 : 0.54);
+    // (the adaptive instances are bound by arithmetic, not by load latency: equal shares -- 117.5 -> 109.9 us at 2^20 envs, round 4)
+    const double f = forced >= 0.0 ? forced : (integrator == R6_EULER ? 0.56 : (integrator == R6_RK45 ? 0.5 : 0.54));
     if (!(f > 0.0) || f == 0.5 || f >= 1.0) return 0u;
     return (uint32_t)(f * 65536.0 + 0.5);
 }
@@ -1767,6 +1780,14 @@ int r6_internal_test_pair_abort(int raise) {
     if (!h) return 0;
     *reinterpret_cast<volatile int*>(h) = raise ? 1 : 0;
     return 1;
+}
+// test hook: where the hardware puts the waves of a workgroup of step_k_pair_kernel's shape.  out[(block * waves + w) * 2] = HW_ID,
+// [.. + 1] = XCC_ID of wave w.  The pair kernel runs waves w, w + 4, w + 8 of a 768-thread workgroup as the dynamics and reward waves
+// of ONE tile and counts on their sharing a SIMD (HW_ID.simd_id) for speed -- never for a result; tests/test_gpu_step_k.py watches it.
+int r6_internal_test_wave_placement(uint32_t* out, int blocks, void* stream) {
+    if (!out || blocks < 1) return R6_E_BADARG;
+    hipLaunchKernelGGL(r6::wave_placement_kernel, dim3((unsigned)blocks), dim3(r6::kPairBlock), 0, static_cast<hipStream_t>(stream), out);
+    return check_launch("r6_internal_test_wave_placement");
 }
 #endif
 size_t r6_policy_net_size(void) { return sizeof(R6PolicyNet); }

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Collects round 4's A/B records from gpurun_out/ (scratch) into profiles/r4_experiments.json (tracked).  Every record: the
+command's log file, what was compared, and the POOLED lines of scripts/ab_swap.py (median of the per-round means over all envs;
+one env = one set of buffers stepped by every build / shape in turn)."""
+import json, os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+
+
+def pooled(name):
+    p = os.path.join(G, name)
+    if not os.path.exists(p):
+        return None
+    out = {}
+    for l in open(p, errors="replace"):
+        m = re.match(r"POOLED (\S+)\s+us/step median\s+([\d.]+) \(([+-][\d.]+) vs [^)]*\) lower-half mean\s+([\d.]+) min\s+([\d.]+)\s+frac ([\d.]+)", l)
+        if m:
+            out[m.group(1)] = {"median_us": float(m.group(2)), "delta_vs_first_us": float(m.group(3)), "lower_half_mean_us": float(m.group(4)),
+                               "min_us": float(m.group(5)), "hbm_frac": float(m.group(6))}
+    return out or None
+
+
+def lines(name, pat):
+    p = os.path.join(G, name)
+    return [l.rstrip() for l in open(p, errors="replace") if re.search(pat, l)] if os.path.exists(p) else None
+
+
+E = {
+ "method": "scripts/ab_swap.py: ONE env (one set of buffers) whose library handle / r6_tune shape is swapped between timing rounds of 200 launches "
+           "(HIP events), rounds interleaved, every other round in reverse order; 2-3 separately allocated envs pooled.  Separate envs differ by "
+           "+-3 % from their allocations alone (scripts/launch_shape_ab.py, the round-3 harness, compared builds on separate envs: its records of "
+           "this round are kept for the bit-exactness checks only).  N = 2^20 envs, RK4 dt 0.1, raw env unless said otherwise.  Code of every "
+           "experiment: the commit named in its record; default builds do not contain them.",
+ "headline_fixed_structure (review round 3, Next 2)": {
+  "a_reset_drain_without_the_workgroup_barrier": {
+   "commit": "c9001c0",
+   "what": "old = round 3's kernel (per-workgroup LDS queue, s_waitcnt + workgroup barrier + dense drain at the end of the launch); "
+           "d1 / inl1 = every wave re-samples its own finished envs (wave-cooperative Philox, sample_ic_wave) right behind the request for its next tile, "
+           "no queue, no barrier, no drain; inl2 = the same one tile later (no wait for the tile's own stores); rot = old with the draining wave rotated "
+           "over the four SIMDs of a CU",
+   "separate_envs_rk4_raw (launch_shape_ab)": lines("r4_ab_drain.log", r"^d[01]\s"),
+   "separate_envs_all_variants (launch_shape_ab: rk4 raw | euler | fused stack)": lines("r4_ab_hot.log", r"^(old|hot0|rot|inl2)\s") ,
+   "same_buffers_rk4_raw": pooled("r4_swap_rk4.log"), "same_buffers_euler": pooled("r4_swap_euler.log"), "same_buffers_fused_stack": pooled("r4_swap_wrapped.log"),
+   "result": "in-loop re-sampling +3.4 ... +4.1 us (44 % of the tiles have a finished env: ~1.3 wave-wide Philox passes of ~120 instructions each in "
+             "those tiles on EVERY SIMD, against one dense pass of one wave per workgroup); rotating the draining wave +0.5 / -0.0 / +0.1 us: no gain"},
+  "b_last_round_hand_out": {
+   "commit": "d51f2ad",
+   "what": "the last 3-30 % of the tiles not on any wave's list: pulled in the final round from 32 self-resetting counters (one per group of 40 workgroups "
+           "of an XCD), one returning atomic per tile, issued a tile ahead; bit-identical results checked (raw and fused stack)",
+   "bit_exact": lines("r4_dyn_check.log", "bit-exact") , "same_buffers": pooled("r4_swap_dyn.log"),
+   "result": "-0.14 ... +0.58 us over dyn = 0.03 ... 0.2; +0.6 ... +0.7 without the static XCD split: no gain"},
+  "c_kernarg_diet": {
+   "commit": "c9001c0",
+   "what": "microbenchmark (scripts/kernarg_bench.hip: 656 B by value | pointer to a device copy | 24 B, launches of the step's shape streaming 0 / 32 / 128 MB) "
+           "and, in the product kernel, the hot prologue arguments first as scalars, preloaded into SGPRs by the command processor "
+           "(-mllvm -amdgpu-kernarg-preload-count=16; `pre`) or not (`nopre`), against the by-value structs (`hot0`)",
+   "microbenchmark": lines("r4_kernarg_bench.log", "us/launch"),
+   "product_kernel_same_buffers": "see a.same_buffers_*: pre +0.64 / +0.08 / +0.27 us, nopre +1.00 / +0.16 / +0.27 us (rk4 raw / euler / fused stack)",
+   "result": "a pointer instead of the by-value struct changes nothing (39.28 vs 39.28 us at 128 MB per launch); the preloaded form is 0.6 us SLOWER in the "
+             "RK4 instance (68 instead of 57 SGPR spills): no gain"},
+  "launch_shapes_tried_on_top": {"what": "grid of 1024 workgroups (exactly four tiles per wave), register prefetch at four (pf4) and five (pf5) waves per SIMD",
+                                 "same_buffers": pooled("r4_swap_grid.log"), "result": "+2.3 ... +2.5, +3.2, +5.2 us"},
+  "stop": "(a) + (b) + (c) together move the in-process median by less than 1 us in the best case and by +0.6 ... +4 us otherwise: per the review's stop rule the "
+          "headline kernel's launch structure is left as it is (DESIGN.md section 4)"},
+ "large_N (review Next 3)": {
+  "streaming_stores_by_size": {str(n): pooled(f"r4_nt_n{n}.log") for n in (1310720, 1572864, 1835008, 2097152, 2621440, 3145728, 3407872, 4194304, 5242880, 6291456)},
+  "prefetch_and_nt_variants": {str(n): pooled(f"r4_swap_n{n}.log") for n in (2097152, 4194304, 8388608)},
+  "balanced_grid_tiles_per_wave": {str(n): pooled(f"r4_tpw2_n{n}.log") for n in (4194304, 6291456, 8388608, 12582912)},
+  "balanced_grid_tiles_per_wave_first_sweep": {str(n): pooled(f"r4_tpw_n{n}.log") for n in (4194304, 8388608, 16777216)},
+  "8M_priority_ladder_and_tiles_per_wave": pooled("r4_swap_8m.log"),
+  "result": "streaming (non-temporal) output stores now also for 1.2-2.36 M envs: 2^21 envs 81.2 -> 73.0 us (0.59 -> 0.65-0.68 of the HBM peak); the register "
+            "prefetch loses at every size (2^21 +2.7 ... +7, 2^22 +12 ... +14, 2^23 +21 us); the dispatcher-balanced grid takes four tiles per wave from "
+            "6.3 M envs on (2^23: -3.8 / -9.4 / -6.1 us in three sessions, neighbours unchanged)"},
+ "rk45 (review Next 5)": {
+  "what": "old = round 3 (7 x 13 stage values, 254 VGPRs, IEEE sqrt / division / powf in the step control); w1 / w3 / w4 = stage vectors cut to the 9 "
+          "force-dependent components (position rows and omega_x derived, mass analytic) compiled for 1 / 3 / 4 waves per SIMD; fw3 / fw4 = + hardware rcp / "
+          "sqrt / exp2 / log2 in the step-size control (attempt loop 1438 -> 984 instructions)",
+  "same_buffers_first": pooled("r4_swap_rk45.log"), "same_buffers_second": pooled("r4_swap_rk45b.log"), "launch_shapes": pooled("r4_swap_rk45c.log"),
+  "parity": lines("r4_call7.log", r"rk45|nfev")},
+}
+json.dump(E, open(os.path.join(ROOT, "profiles", "r4_experiments.json"), "w"), indent=1)
+print("ok", sum(1 for _ in open(os.path.join(ROOT, "profiles", "r4_experiments.json"))), "lines")
