@@ -49,5 +49,36 @@ if os.path.isdir(pmc):
                        "kernel_cycles_under_pmc (GRBM_GUI_ACTIVE / 8 XCDs)": cyc,
                        "valu_busy_fraction (4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / kernel cycles)": 4 * res.get("SQ_ACTIVE_INST_VALU", 0) / 1024 / cyc if cyc else None,
                        "mean_resident_waves_per_simd (SQ_WAVE_CYCLES * 4 / 1024 / kernel cycles)": 4 * res.get("SQ_WAVE_CYCLES", 0) / 1024 / cyc if cyc else None}}
+    # the VALU work priced at the MEASURED issue rates (bench.py valu_issue_time_us), not at the quad-cycle SQ_ACTIVE_INST_VALU ticks in
+    sys.path.insert(0, ROOT)
+    import bench
+    insts, trans = res.get("SQ_INSTS_VALU", 0.0), res.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    t = bench.valu_issue_time_us(insts, trans)
+    out["derived"]["transcendental_instructions_per_tile"] = trans / tiles
+    out["derived"]["valu_issue_time_us_per_simd (measured rates: 1.2 ns plain, 1.8 ns scalar source x assumed share, 3.4 ns transcendental)"] = t["priced_us"]
+    out["derived"]["valu_issue_time_floor_us_per_simd (all at 1.2 ns)"] = t["floor_us"]
+    wc = res.get("SQ_WAVE_CYCLES", 0.0)
+    if wc:
+        out["derived"]["share_of_wave_cycles"] = {"issuing (SQ_ACTIVE_INST_ANY)": res.get("SQ_ACTIVE_INST_ANY", 0) / wc, "waiting in s_waitcnt (SQ_WAIT_ANY)": res.get("SQ_WAIT_ANY", 0) / wc,
+                                                   "issue stall (SQ_WAIT_INST_ANY)": res.get("SQ_WAIT_INST_ANY", 0) / wc}
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc_valu.json"), "w"), indent=1)
+stepk = os.path.join(ROOT, "gpurun_out", f"pmc_stepk_{tag}", "summary.json")
+if os.path.exists(stepk):
+    raw = json.load(open(stepk))
+    line = raw.pop("driver_line", None)
+    wc, tiles_k, K = raw.get("SQ_WAVE_CYCLES", 0.0), 1024.0, 16.0
+    d = {"waves_per_launch": raw.get("SQ_WAVES"), "waves_per_simd": (raw.get("SQ_WAVES") or 0) / 1024.0,
+         "valu_instructions_per_tile_and_env_step": raw.get("SQ_INSTS_VALU", 0) / tiles_k / K,
+         "salu_instructions_per_tile_and_env_step": raw.get("SQ_INSTS_SALU", 0) / tiles_k / K,
+         "lds_instructions_per_tile_and_env_step": raw.get("SQ_INSTS_LDS", 0) / tiles_k / K}
+    if wc:
+        d["share_of_wave_cycles"] = {"valu_issue": raw.get("SQ_ACTIVE_INST_VALU", 0) / wc, "scalar_issue": raw.get("SQ_ACTIVE_INST_SCA", 0) / wc,
+                                     "lds_issue": raw.get("SQ_ACTIVE_INST_LDS", 0) / wc, "waiting_s_waitcnt_or_sleep": raw.get("SQ_WAIT_ANY", 0) / wc,
+                                     "issue_stall": raw.get("SQ_WAIT_INST_ANY", 0) / wc}
+    json.dump({"kernel": "r6::step_k_pair_kernel<0,0,14> (Euler, acceleration shaping, 14-wide obs): three waves per 64-env tile -- one for the dynamics / reset / "
+                         "observation, two for the reward of alternate steps -- on one SIMD",
+               "workload": "BASELINE configs[1]: 65 536 envs, Euler dt 0.04, r6_step_k with K = 16 steps per launch, all per-step outputs stored (scripts/stepk_driver.py)",
+               "method": "scripts/pmc_stepk.sh: rocprofv3 --kernel-trace --pmc <group>, one counter group per run, mean over the last 30 launches",
+               "commit": summ.get("commit"), "driver_line": line, "raw_per_launch": raw, "derived": d},
+              open(os.path.join(dst, f"{tag}_pmc_stepk.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_traffic.json")).read())
