@@ -65,7 +65,11 @@ if os.path.isdir(pmc):
 stepk = os.path.join(ROOT, "gpurun_out", f"pmc_stepk_{tag}", "summary.json")
 if os.path.exists(stepk):
     raw = json.load(open(stepk))
-    line = raw.pop("driver_line", None)
+    raw.pop("driver_line", None)
+    g1 = os.path.join(ROOT, "gpurun_out", f"pmc_stepk_{tag}", "g1.log")
+    line = next((l.strip() for l in reversed(open(g1, errors="replace").read().split("\n")) if "env-steps/s" in l), None) if os.path.exists(g1) else None
+    if line:
+        line += "   (wall time per launch UNDER counter collection, which serialises launches: not a throughput figure)"
     wc, tiles_k, K = raw.get("SQ_WAVE_CYCLES", 0.0), 1024.0, 16.0
     d = {"waves_per_launch": raw.get("SQ_WAVES"), "waves_per_simd": (raw.get("SQ_WAVES") or 0) / 1024.0,
          "valu_instructions_per_tile_and_env_step": raw.get("SQ_INSTS_VALU", 0) / tiles_k / K,
