@@ -235,6 +235,10 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #ifndef R6_RK4_WAVES
 #define R6_RK4_WAVES 5
 #endif
+#ifndef R6_RK4_SUBSTEP_WAVES
+#define R6_RK4_SUBSTEP_WAVES 4   // RK4 with several sub-steps per env step: the loop-carried state does not fit the 96 registers of five waves
+                                 // (round 3: two registers spilled to scratch); these instances are compiled for four
+#endif
 #ifndef R6_RK45_WAVES
 #define R6_RK45_WAVES 4    // waves per SIMD the adaptive instances are compiled for (128 registers; round 3: 1 -> 254 registers, two waves)
 #endif
@@ -245,7 +249,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 // __launch_bounds__(256, 5): 5 waves per SIMD = a 96-VGPR budget (the RK4 instance would take 101 and drop
 // to 4 waves; the cap costs no scratch).  Measured A/B at N = 2^20: 46.7 -> 44.0 us.
 template <int INTEG, int SHAPING, int OD, bool NT = false, bool ONE = false>
-__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG == R6_EULER ? R6_EULER_WAVES : R6_RK4_WAVES))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
+__global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG == R6_EULER ? R6_EULER_WAVES : (ONE ? R6_RK4_WAVES : R6_RK4_SUBSTEP_WAVES)))) void step_kernel(const R6Params p, const R6Buffers b, const uint64_t seed,
                                                       const uint64_t step_index, const uint64_t env_offset,
                                                       const uint32_t even_share_q16, const uint32_t sweep) {
     // Hot scalars are read from `p` / `b` directly (SGPRs, hoisted out of the tile loop by the
@@ -1529,7 +1533,7 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + r6::kBlock - 1) / 
 // Resident capacity (workgroups) of the current device for one step-kernel instance, cached.
 template <typename K>
 int resident_blocks(K kernel, int slot) {
-    static std::atomic<int> cache[16][32];
+    static std::atomic<int> cache[16][48];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     int v = cache[dev][slot].load(std::memory_order_relaxed);
@@ -1617,7 +1621,8 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
         if (p.n_substeps == 1) kernel = nt ? r6::step_kernel<INTEG, SHAPING, OD, true, true> : r6::step_kernel<INTEG, SHAPING, OD, false, true>;
         else if (nt) kernel = r6::step_kernel<INTEG, SHAPING, OD, true, false>;
     }
-    const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0);   // both forms share launch bounds and occupancy
+    // occupancy cache slot: the sub-stepped RK4 instances have their own launch bounds
+    const int slot = INTEG * 4 + SHAPING * 2 + (OD == 14 ? 1 : 0) + ((INTEG == R6_RK4 && p.n_substeps != 1) ? 32 : 0);
     const int64_t n_tiles = (b.n + 63) / 64;
     int64_t blocks = (n_tiles + r6::kWaves - 1) / r6::kWaves;
     int64_t cap = resident_blocks(kernel, slot);

@@ -1,0 +1,32 @@
+"""`python bench.py --gpus 2` from a plain shell on the GPU box: the launcher branch with REAL ranks (round-3 review, item 1).  Two ranks
+share the one GPU a builder's box has (R6_FORCE_DEVICE=0) and talk over gloo (RCCL refuses two ranks on one device); everything
+else -- the child torch.distributed.run, the env shards with their global offsets, the timed loops between barriers, the reduction
+of the per-rank times, the rollout-gather loop -- is what an 8-GPU run executes.  The loop served: main_6DOF.py:105-139."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_gpus_2_launches_two_ranks_on_this_gpu():
+    env = dict(os.environ, R6_DIST_BACKEND="gloo", R6_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs-per-gpu", "65536", "--steps", "64", "--warmup", "16",
+                        "--burnin", "200", "--gather-every", "16"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip() == lines[0], "the launcher's stdout is the ONE JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["envs_total"] == 2 * 65536 and line["scaling"] == "weak"
+    rc = line["rccl"]
+    assert rc["rccl_ranks"] == 2 and rc["backend"] == "gloo" and rc["devices"] == [0, 0] and rc["verified_with_more_than_one_rank"] is True
+    assert rc["with_rollout_gather"]["gathers"] >= 2 and rc["with_rollout_gather"]["episodes_seen"] > 0
+    assert line["value"] > 1e8 and line["roofline"]["kernel_us"] > 0
+    assert "cpu_baseline" not in line and "out_of_cache" not in line          # N = 1 extras stay out of the N > 1 record
