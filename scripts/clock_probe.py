@@ -16,11 +16,18 @@ for integ in ("rk4", "euler"):
     for k in range(3000):
         env.step_async(pool[k % 2])
     for rep in range(4):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         for k in range(500):
             env.step_async(pool[k % 2])
+        ev1.record()
         torch.cuda.synchronize()
+        us = ev0.elapsed_time(ev1) / 500 * 1e3
         st = env.stats.cpu().numpy()[:1280]
         cyc, ticks = st[:, 0], st[:, 1]
         ghz = cyc / (ticks * 10.0)
         span = (st[:, 3].max() - st[:, 2].min()) / 100.0
-        print(f"{integ}: clock median {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}); workgroup life mean {ticks.mean() / 100:.2f} us, launch span {span:.2f} us")
+        # algorithmic bytes per shader clock and CU: 201 B per env-step here (episode tracking on) over launch-to-launch time
+        bpc = 201.0 * n / (us * 1e-6) / 256 / (np.median(ghz) * 1e9)
+        print(f"{integ}: clock median {np.median(ghz):.3f} GHz (p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}); workgroup life mean {ticks.mean() / 100:.2f} us, "
+              f"launch span {span:.2f} us, launch to launch {us:.2f} us = {201.0 * n / us * 1e-6:.2f} TB/s = {bpc:.2f} B per clock and CU")
