@@ -62,6 +62,11 @@ E = {
                                  "same_buffers": pooled("r4_swap_grid.log"), "result": "+2.3 ... +2.5, +3.2, +5.2 us"},
   "stop": "(a) + (b) + (c) together move the in-process median by less than 1 us in the best case and by +0.6 ... +4 us otherwise: per the review's stop rule the "
           "headline kernel's launch structure is left as it is (DESIGN.md section 4)"},
+ "launch_shape_constants_resweep (one set of buffers, 3 envs x 11 rounds; a fast box: base 35.34 us = 0.70)": {
+  "rk4_raw": pooled("r4_swap_tune.log"), "fused_stack": pooled("r4_swap_tune_w.log"),
+  "result": "the defaults stand: even-XCD share 0.54-0.56 (0.50 +0.7, 0.58 +0.7, 0.60 +1.7 us), grid 1280 workgroups (1216 +0.7, 1152 +1.4), fixed tile order "
+            "(+0.2 ... +0.3 otherwise), priority ladder (+4.0 without), plain output stores at 2^20 (+0.6 streaming)"},
+ "clock_probe (scripts/clock_probe.py, -DR6_CLOCK_PROBE builds, fused-stack buffers: 201 B per env-step)": lines("r4_call15.log", r"clock median"),
  "large_N (review Next 3)": {
   "streaming_stores_by_size": {str(n): pooled(f"r4_nt_n{n}.log") for n in (1310720, 1572864, 1835008, 2097152, 2621440, 3145728, 3407872, 4194304, 5242880, 6291456)},
   "prefetch_and_nt_variants": {str(n): pooled(f"r4_swap_n{n}.log") for n in (2097152, 4194304, 8388608)},
