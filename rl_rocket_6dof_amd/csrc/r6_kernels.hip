@@ -1094,8 +1094,14 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : 4)) voi
 #ifndef R6_PAIR_NB
 #define R6_PAIR_NB 2   // reward waves per tile: wave B_j takes the steps with seq % NB == j (the reward is the longer half of a step)
 #endif
-constexpr int kPairTiles = 4, kPairNB = R6_PAIR_NB, kPairBlock = 64 * kPairTiles * (1 + kPairNB), kRing = R6_PAIR_RING, kSlotWords = 21;
+#ifndef R6_PAIR_OBS_WAVE
+#define R6_PAIR_OBS_WAVE 1   // a fourth wave per tile (C) takes every per-step store of the dynamics wave: observation (through an LDS tile, as wide
+                             // stores), terminal observation, done / flag bytes.  0 = round 3's three waves (A stores them itself, lane by lane)
+#endif
+constexpr int kPairTiles = 4, kPairNB = R6_PAIR_NB, kPairC = R6_PAIR_OBS_WAVE ? 1 : 0, kPairBlock = 64 * kPairTiles * (1 + kPairNB + kPairC),
+              kRing = R6_PAIR_RING, kSlotWords = 21;
 static_assert(kRing >= 2 * kPairNB, "the ring holds at least two steps per reward wave");
+static_assert(kPairBlock <= 1024, "one workgroup");
 
 // LDS words shared by the two waves of a pair.  The pointers carry the LDS address space explicitly: through a generic pointer
 // the poll becomes a flat load, which counts in vmcnt and would make every poll wait for the wave's outstanding global loads / stores.
@@ -1119,14 +1125,23 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     __shared__ float ring[kPairTiles][kRing][kSlotWords][64];
     __shared__ float ep_run[kPairTiles][64];                               // running episode return of a tile's envs, handed from reward wave to reward wave
     __shared__ int produced[kPairTiles], consumed[kPairTiles][kPairNB], returned[kPairTiles], abort_word;
+    // wave C (R6_PAIR_OBS_WAVE): the first observation of the episodes wave A started in a step (rows of the reset lanes only), published
+    // behind A's reset with `produced2`; C's own transposing tile; C's release of a slot.
+    // (Also measured: C drawing Rocket6DOF.reset's initial conditions for EVERY env two steps ahead -- the draw depends on (seed, env,
+    // step) only -- so that A merely picks them up: correct, and 2.43 -> 3.01 us per step at K = 16: ~300 instructions per step on the
+    // SIMD the chain runs on, against ~70 for the draws actually needed.)
+    __shared__ float rs_obs[kPairC ? kPairTiles : 1][kPairC ? kRing : 1][kPairC ? OD : 1][64];
+    __shared__ __attribute__((aligned(16))) float ctile[kPairC ? kPairTiles : 1][kPairC ? 64 * OD : 4];
+    __shared__ int produced2[kPairTiles], consumed_c[kPairTiles];
     __shared__ float lds_inv_norm[R6_STATE_DIM];
     __shared__ stat_t blk_stats[R6_NUM_STATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool role_b = wave >= kPairTiles;
-    const int slot_of = wave % kPairTiles;                      // the tile slot within the workgroup (waves t, t + 4, t + 8 share SIMD t)
+    const bool role_c = kPairC != 0 && wave >= kPairTiles * (1 + kPairNB);
+    const bool role_b = wave >= kPairTiles && !role_c;
+    const int slot_of = wave % kPairTiles;                      // the tile slot within the workgroup (waves t, t + 4, t + 8 (, t + 12) share SIMD t)
     const int par = role_b ? wave / kPairTiles - 1 : 0;         // reward wave j of the tile
     const int64_t n = b.n, ld = b.ld;
     const int64_t n_tiles = (n + 63) >> 6;
@@ -1148,6 +1163,8 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     if (tid < kPairTiles) {
         produced[tid] = 0;
         returned[tid] = 0;
+        produced2[tid] = 0;
+        consumed_c[tid] = 0;
 #pragma unroll
         for (int j = 0; j < kPairNB; ++j) consumed[tid][j] = 0;
     }
@@ -1164,7 +1181,7 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
         const bool live = lane < rem;
         const int64_t i = e0 + lane;
         const int lane_ld = live ? lane : 0;
-        if (!role_b) {
+        if (!role_b && !role_c) {
             // ================================= wave A: what the next step needs ==========================================
             float y[kDyn], mass = 4.0e4f, m0 = 4.0e4f, v0 = 0.0f;
             uint32_t ep_step = 0u;
@@ -1224,6 +1241,10 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                         ok = false;
                         break;
                     }
+                    if (kPairC && sp >= 0 && !PKWAIT(pair_wait((lds_word_t)&consumed_c[slot_of], sp + 1, (lds_word_t)&abort_word))) {
+                        ok = false;
+                        break;
+                    }
                 }
                 {
                     float(*sl)[64] = ring[slot_of][seq % kRing];
@@ -1241,6 +1262,38 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __atomic_store_n((lds_word_t)&produced[slot_of], seq + 1, __ATOMIC_RELAXED);
 
+                if constexpr (kPairC != 0) {
+                    // ---- wave C stores this step's outputs; A only starts the next episodes (Rocket6DOF.reset) and hands C their first
+                    //      observation: no global store of A's inside the K loop ----
+                    asm volatile("" : "+v"(n0), "+v"(n1), "+v"(n2));   // the prefetch has arrived
+                    if (p.auto_reset) {
+                        uint64_t fin = __ballot(live && done);
+                        if (fin != 0ull) {
+#ifdef R6_TRACE_K
+                            ++pk_ends;
+#endif
+                            const R6Params pp = load_params();
+                            float(*rs)[64] = rs_obs[slot_of][seq % kRing];
+                            do {
+                                const int j = __builtin_ctzll(fin);
+                                fin &= fin - 1ull;
+                                float ic[R6_STATE_DIM];
+                                sample_ic_wave(pp, seed, env_offset + (uint64_t)(e0 + j), step_index + (uint64_t)k + step_base, lane, ic);
+                                if (lane == j) {
+#pragma unroll
+                                    for (int q = 0; q < kDyn; ++q) y[q] = ic[q];
+                                    mass = m0 = ic[13];
+                                    v0 = sqrtf(fmaf(ic[3], ic[3], fmaf(ic[4], ic[4], ic[5] * ic[5])));
+                                    ep_step = 0u;
+#pragma unroll
+                                    for (int q = 0; q < OD; ++q) rs[q][lane] = ic[q] * lds_inv_norm[q];
+                                }
+                            } while (fin != 0ull);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) __atomic_store_n((lds_word_t)&produced2[slot_of], seq + 1, __ATOMIC_RELAXED);
+                        }
+                    }
+                } else {
                 // ---- observation, terminal observation, reset ----
                 float ob[OD];
 #pragma unroll
@@ -1290,6 +1343,7 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
 #pragma unroll
                     for (int j = 0; j < OD; ++j) dst[j] = ob[j];
                 }
+                }   // !kPairC
                 a0 = n0;
                 a1 = n1;
                 a2 = n2;
@@ -1308,6 +1362,77 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                 uniform_ptr(b.epconst + e0)[lane] = m0;
                 uniform_ptr(b.epconst + (ld + e0))[lane] = v0;
                 if (has_ep) uniform_ptr(b.ep_step + e0)[lane] = ep_step;
+            }
+        } else if (role_c) {
+            // ================================= wave C: this step's stores =================================================
+            // done / flag bytes, terminal observation, observation (the fresh episode's first one for a lane wave A has reset) -- from
+            // the state wave A published, through this wave's own LDS tile as contiguous 16-byte stores.  Nothing waits for C but the
+            // slot's next use: the stores (round 3: lane by lane from wave A, 0.9 of a step's 2.4 us) are off the chain of the K steps.
+            float* const tile = ctile[slot_of];
+            const bool full = rem >= 64;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k, ++seq) {
+                const bool emit = !last_only || k + 1 == K;
+                if (!PKWAIT(pair_wait((lds_word_t)&produced[slot_of], seq + 1, (lds_word_t)&abort_word))) {
+                    ok = false;
+                    break;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float ob[OD];
+                int fl;
+                {
+                    const float(*sl)[64] = ring[slot_of][seq % kRing];
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) {
+                        if (j < OD) ob[j] = sl[j][lane] * lds_inv_norm[j];
+                    }
+                    if (OD == 14) ob[OD - 1] = sl[13][lane] * lds_inv_norm[13];
+                    fl = __float_as_int(sl[19][lane]);
+                }
+                const bool ground = (fl & 1) != 0, bnd = (fl & 2) != 0, truncated = (fl & 4) != 0, done = (fl & 8) != 0;
+                if (live && emit) {
+                    uniform_ptr(b.done + ((int64_t)k * sk.done_stride + e0))[lane] = done ? 1 : 0;
+                    if (b.flags)
+                        uniform_ptr(b.flags + ((int64_t)k * sk.flags_stride + e0))[lane] =
+                            (uint8_t)((ground ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
+                    if (b.nfev) uniform_ptr(b.nfev + ((int64_t)k * sk.nfev_stride + e0))[lane] = (uint8_t)(INTEG == R6_RK4 ? 4 : 1);
+                }
+                if (live && done && p.auto_reset && emit && b.final_obs) {
+                    float* fo = b.final_obs + ((int64_t)k * sk.final_obs_stride + i * OD);
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) fo[j] = ob[j];
+                }
+                if (p.auto_reset && __any(live && done)) {   // wave A has reset these lanes: their row is the new episode's first observation
+                    if (!PKWAIT(pair_wait((lds_word_t)&produced2[slot_of], seq + 1, (lds_word_t)&abort_word))) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (live && done) {
+                        const float(*rs)[64] = rs_obs[slot_of][seq % kRing];
+#pragma unroll
+                        for (int q = 0; q < OD; ++q) ob[q] = rs[q][lane];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the slot's reads are done
+                if (lane == 0) __atomic_store_n((lds_word_t)&consumed_c[slot_of], seq + 1, __ATOMIC_RELAXED);
+#pragma unroll
+                for (int j = 0; j < OD; ++j) tile[lane * OD + j] = ob[j];
+                wave_lds_sync();
+                if (emit) {
+                    const gptr<float> dst = uniform_ptr(b.obs + ((int64_t)k * sk.obs_stride + e0 * OD));
+                    if (full) {
+                        constexpr int n4 = 64 * OD / 4;
+#pragma unroll
+                        for (int r = 0; r < (n4 + 63) / 64; ++r) {
+                            const int q = lane + 64 * r;
+                            if (q < n4) *(gptr<f4>)(dst + 4 * q) = ld4(&tile[4 * q]);
+                        }
+                    } else {
+                        for (int q = lane; q < (int)rem * OD; q += 64) dst[q] = tile[q];
+                    }
+                }
+                wave_lds_sync();
             }
         } else {
             // ================================= wave B: reward, records =====================================================

@@ -238,8 +238,9 @@ def test_one_buffer_for_all_steps_keeps_the_last_step(cfg):
 
 
 def test_waves_of_a_tile_share_a_simd():
-    """step_k_pair_kernel runs waves w, w + 4, w + 8 of a 768-thread workgroup as the three waves of ONE tile and counts on the
-    hardware placing them on the same SIMD (the dynamics wave's issue slots are what the reward waves fill).  Results never depend
+    """step_k_pair_kernel runs waves w, w + 4, w + 8, w + 12 of a 1024-thread workgroup as the four waves of ONE tile (dynamics, two
+    reward waves, the output wave) and counts on the hardware placing them on the same SIMD (the dynamics wave's idle issue slots
+    are what the others fill).  Results never depend
     on it (the hand-off is LDS counters), the speed does: this test watches the assumption (HW_ID bits 5:4 = simd_id on gfx9),
     with the -DR6_TEST_HOOKS build."""
     import ctypes as C
@@ -252,7 +253,7 @@ def test_waves_of_a_tile_share_a_simd():
     if not os.path.exists(build.TEST_HOOKS_LIB):
         pytest.skip("libr6dof_testhooks.so not built")
     lib = _lib.load(build.TEST_HOOKS_LIB)
-    blocks, waves = 256, 12
+    blocks, waves = 256, 16
     out = torch.zeros((blocks, waves, 2), dtype=torch.int32, device="cuda:0")
     fn = lib.r6_internal_test_wave_placement
     fn.argtypes, fn.restype = [C.c_void_p, C.c_int, C.c_void_p], C.c_int
@@ -264,7 +265,7 @@ def test_waves_of_a_tile_share_a_simd():
     same = 0
     for b in range(blocks):
         assert len(set(cu[b].tolist())) == 1, "a workgroup lives on one CU"
-        same += int(all(simd[b, w] == simd[b, w + 4] == simd[b, w + 8] for w in range(4)))
+        same += int(all(simd[b, w] == simd[b, w + 4] == simd[b, w + 8] == simd[b, w + 12] for w in range(4)))
         assert sorted(simd[b, :4].tolist()) == [0, 1, 2, 3], f"block {b}: the first four waves do not cover the four SIMDs: {simd[b].tolist()}"
-    print(f"[pair placement] {same} of {blocks} workgroups have waves w, w + 4, w + 8 on one SIMD")
-    assert same == blocks, f"only {same} of {blocks} workgroups place waves w, w + 4, w + 8 on one SIMD: the pair kernel's speed assumption no longer holds"
+    print(f"[pair placement] {same} of {blocks} workgroups have waves w, w + 4, w + 8, w + 12 on one SIMD")
+    assert same == blocks, f"only {same} of {blocks} workgroups place waves w, w + 4, w + 8, w + 12 on one SIMD: the pair kernel's speed assumption no longer holds"
