@@ -1715,6 +1715,7 @@ struct StepTune {
         if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) even_share = std::atof(e);
         if (const char* e = std::getenv("R6_GRID_BLOCKS")) grid_blocks = std::atoi(e);
         if (const char* e = std::getenv("R6_SWEEP")) sweep = std::atoi(e);
+        if (const char* e = std::getenv("R6_BALANCED_TPW")) balanced_tpw = std::atoi(e);
     }
 };
 StepTune& tune() {
