@@ -284,7 +284,9 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // (-amdgpu-kernarg-preload-count), +0.6; a 1024-workgroup grid with exactly four tiles per wave, +2.3; the register
     // prefetch at four and five waves per SIMD, +3.2 / +5.2; the last 3-20 % of the tiles handed out in the final round from 32
     // self-resetting counters, claimed a tile ahead, -0.1 ... +0.6 (code at commit d51f2ad).  None moved the launch by the
-    // 1 us the review's stop rule asks for: DESIGN.md section 4.)
+    // 1 us the review's stop rule asks for: DESIGN.md section 4.  Also measured: the next tile requested in the MIDDLE of a tile, between
+    // the dynamics and the reward phase (the stages of the dynamics decide the register budget): the reward phase does not have the 18
+    // registers free either -- 25-48 spills to scratch, +9.6 ... +19 us.)
     int64_t nw = (int64_t)gridDim.x * kWaves;
     int64_t t_first = (int64_t)blockIdx.x * kWaves + wave;
     int64_t pool_base = 0, pool_tiles = n_tiles;

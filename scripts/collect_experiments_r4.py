@@ -60,6 +60,9 @@ E = {
              "RK4 instance (68 instead of 57 SGPR spills): no gain"},
   "launch_shapes_tried_on_top": {"what": "grid of 1024 workgroups (exactly four tiles per wave), register prefetch at four (pf4) and five (pf5) waves per SIMD",
                                  "same_buffers": pooled("r4_swap_grid.log"), "result": "+2.3 ... +2.5, +3.2, +5.2 us"},
+  "mid_tile_prefetch (not in any commit: the next tile requested between the dynamics and the reward phase of the current one; m1 = waited for in front of the "
+  "stores, m2 = not; 48 / 25 VGPR spills to scratch under the 96-register budget of five waves per SIMD)": {"2^20": pooled("r4_swap_mid.log"), "2^23": pooled("r4_swap_mid_8m.log"),
+                                                                                                              "result": "+9.6 ... +19 us at 2^20, +89 ... +226 us at 2^23"},
   "stop": "(a) + (b) + (c) together move the in-process median by less than 1 us in the best case and by +0.6 ... +4 us otherwise: per the review's stop rule the "
           "headline kernel's launch structure is left as it is (DESIGN.md section 4)"},
  "launch_shape_constants_resweep (one set of buffers, 3 envs x 11 rounds; a fast box: base 35.34 us = 0.70)": {
