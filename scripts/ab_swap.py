@@ -21,6 +21,8 @@ ap.add_argument("--dt", type=float, default=None)
 ap.add_argument("--wrapped", action="store_true")
 ap.add_argument("--envs", type=int, default=2)
 ap.add_argument("--pool", type=int, default=2)
+ap.add_argument("--reset-on-swap", type=int, default=0, help="> 0: after every swap the env is reset and stepped this many times before timing (builds that "
+                                                             "interpret the buffers differently)")
 ap.add_argument("--shapes", default="base", help="';'-separated r6_tune settings applied per timing round, e.g. 'base;grid=1024;grid=1024,even=0.5'")
 args = ap.parse_args()
 cfg = default_env_config()
@@ -63,6 +65,10 @@ for ei in range(args.envs):
         for name in (names[::-1] if r % 2 else names):
             env.lib = handles[name.split("|")[0]]
             apply(name.split("|")[1], env.lib)
+            if args.reset_on_swap > 0:
+                env.reset()
+                for j in range(args.reset_on_swap):
+                    env.step_async(pool[j % args.pool])
             for j in range(20):
                 env.step_async(pool[j % args.pool])
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -63,6 +63,9 @@ E = {
   "mid_tile_prefetch (not in any commit: the next tile requested between the dynamics and the reward phase of the current one; m1 = waited for in front of the "
   "stores, m2 = not; 48 / 25 VGPR spills to scratch under the 96-register budget of five waves per SIMD)": {"2^20": pooled("r4_swap_mid.log"), "2^23": pooled("r4_swap_mid_8m.log"),
                                                                                                               "result": "+9.6 ... +19 us at 2^20, +89 ... +226 us at 2^23"},
+  "tiled_state_layout (timing experiment, not in any commit: state as [tile][14][64] instead of [14][ld] in r6_step's loads, stores and resets; one base pointer and "
+  "immediate offsets per tile, 45 instead of 57 SGPR spills; env reset and re-burnt after every swap)": {"2^20": pooled("r4_swap_tiled.log"), "2^21": pooled("r4_swap_tiled_2m.log"), "2^23": pooled("r4_swap_tiled_8m.log"),
+                                                                                                         "result": "2^20 +1.3 us, 2^21 -2.5 us, 2^23 -4.7 us: not worth a layout change"},
   "stop": "(a) + (b) + (c) together move the in-process median by less than 1 us in the best case and by +0.6 ... +4 us otherwise: per the review's stop rule the "
           "headline kernel's launch structure is left as it is (DESIGN.md section 4)"},
  "launch_shape_constants_resweep (one set of buffers, 3 envs x 11 rounds; a fast box: base 35.34 us = 0.70)": {
