@@ -30,3 +30,27 @@ def test_bench_gpus_2_launches_two_ranks_on_this_gpu():
     assert rc["with_rollout_gather"]["gathers"] >= 2 and rc["with_rollout_gather"]["episodes_seen"] > 0
     assert line["value"] > 1e8 and line["roofline"]["kernel_us"] > 0
     assert "cpu_baseline" not in line and "out_of_cache" not in line          # N = 1 extras stay out of the N > 1 record
+
+
+def test_bench_single_gpu_prints_one_contract_line():
+    """`python bench.py` the way the driver runs it at N = 1 (reduced sizes): ONE JSON line on stdout with the contract's keys, the
+    roofline and cpu_baseline objects, and the side figures of this round (rk45, valu at the measured issue rates)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "20", "--burnin", "300", "--cpu-seconds", "1.5"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 100 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.4 < rf["frac"] < 0.9 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["traffic"] and rf["traffic"] > 1.9e8 and "static file" in rf["traffic_source"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 100 and "sample" in cb
+    assert 60 < line["rk45"]["us_per_env_step"] < 300 and line["rk45"]["integrator"] == "rk45"
+    assert "issue_time_us_per_simd" in line["valu"] and "busy_frac" not in line["valu"]
+    assert line["configs1"]["k16"]["roofline"]["bound"] == "dependent_chain_of_one_tile_per_simd"
