@@ -22,7 +22,7 @@ def pooled(name):
 
 def lines(name, pat):
     p = os.path.join(G, name)
-    return [l.rstrip() for l in open(p, errors="replace") if re.search(pat, l)] if os.path.exists(p) else None
+    return [l.rstrip()[:160] for l in open(p, errors="replace") if re.search(pat, l)] if os.path.exists(p) else None
 
 
 E = {
@@ -66,6 +66,12 @@ E = {
   "tiled_state_layout (timing experiment, not in any commit: state as [tile][14][64] instead of [14][ld] in r6_step's loads, stores and resets; one base pointer and "
   "immediate offsets per tile, 45 instead of 57 SGPR spills; env reset and re-burnt after every swap)": {"2^20": pooled("r4_swap_tiled.log"), "2^21": pooled("r4_swap_tiled_2m.log"), "2^23": pooled("r4_swap_tiled_8m.log"),
                                                                                                          "result": "2^20 +1.3 us, 2^21 -2.5 us, 2^23 -4.7 us: not worth a layout change"},
+  "placement_of_the_arrays (scripts/alloc_probe.py: separately allocated envs and slabs with the arrays 0-256 MB apart, skewed by 0-100 KB)": {
+   "2^23": lines("r4_alloc_probe2.log", r"us/step")[:17] if lines("r4_alloc_probe2.log", r"us/step") else None,
+   "2^20": lines("r4_alloc_probe_1m.log", r"us/step"),
+   "non_temporal_state_loads_at_large_N": {str(n): pooled(f"r4_swap_ntl_{n}.log") for n in (8388608, 16777216, 2097152)},
+   "result": "two envs of one process differ by up to 11 % at 2^23 (277 vs 309 us) and 5 % at 2^20, but no spacing / alignment / skew rule reproduces the fast case: "
+             "on one box all 15 slab layouts ran 299-302 us; the spread is not a layout lever.  Non-temporal state loads: +4 % at 2^23 / 2^24"},
   "stop": "(a) + (b) + (c) together move the in-process median by less than 1 us in the best case and by +0.6 ... +4 us otherwise: per the review's stop rule the "
           "headline kernel's launch structure is left as it is (DESIGN.md section 4)"},
  "launch_shape_constants_resweep (one set of buffers, 3 envs x 11 rounds; a fast box: base 35.34 us = 0.70)": {
