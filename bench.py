@@ -511,7 +511,8 @@ def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) 
             "episodes_seen": float(sum(float(t[:, 0].sum()) for t in gathers[n_before:]))}
 
 
-RANK_SCRIPT = os.path.abspath(__file__)     # what every rank of a self-launched job runs (tests point it at a GPU-free stand-in)
+# what every rank of a self-launched job runs (tests point it at a GPU-free stand-in: the attribute, or R6_BENCH_RANK_SCRIPT for a launcher in a process of its own)
+RANK_SCRIPT = os.environ.get("R6_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)
 
 
 def _free_port() -> int:
@@ -542,7 +543,17 @@ def launch_ranks(n_ranks: int, argv, script: str = None) -> int:
     env.setdefault("OMP_NUM_THREADS", "1")
     env["R6_BENCH_LAUNCHER_PID"] = str(os.getpid())
     print(f"[bench] launcher: {n_ranks} ranks, one per GPU: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)   # own process group
+    def _die_with_parent():      # Linux: the job gets SIGTERM when this launcher dies (a driver's timeout kills the launcher only:
+        try:                     # the ranks live in their own session); torch.distributed.run then ends its workers
+            import ctypes
+            import signal
+
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM))      # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True,   # own process group
+                            preexec_fn=_die_with_parent)
     seen = None
     try:
         for ln in proc.stdout:       # rank 0's line goes to stdout as it comes; anything else a rank or a library prints there

@@ -18,6 +18,11 @@ def main():
     assert world is not None and "R6_BENCH_LAUNCHER_PID" in os.environ, "the stub is a rank: it must run under the launcher"
     if os.environ.get("R6_STUB_FAIL_RANK") == os.environ.get("RANK"):
         raise SystemExit(7)
+    if os.environ.get("R6_STUB_PIDDIR"):        # "a rank that runs for a long time": leaves its pid and sleeps
+        import time
+
+        open(os.path.join(os.environ["R6_STUB_PIDDIR"], f"rank{os.environ.get('RANK')}.pid"), "w").write(str(os.getpid()))
+        time.sleep(float(os.environ.get("R6_STUB_SLEEP", "120")))
     import torch.distributed as dist
 
     from rl_rocket_6dof_amd import dist as r6dist

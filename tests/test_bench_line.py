@@ -115,6 +115,46 @@ def test_launcher_process_never_loads_the_gpu_runtime():
     assert "LAUNCH 8 ['--gpus', '8', '--steps', '5']" in r.stdout
 
 
+def test_ranks_do_not_outlive_a_killed_launcher(tmp_path):
+    """A driver that times the bench out kills the LAUNCHER; the ranks live in a session of their own (so that an interrupted launcher
+    can end exactly its own process group) and must not keep their GPUs: the child torch.distributed.run is started with
+    PR_SET_PDEATHSIG and ends its workers when the launcher dies."""
+    import signal
+    import subprocess
+    import time
+
+    env = dict(os.environ, R6_BENCH_RANK_SCRIPT=STUB, R6_STUB_PIDDIR=str(tmp_path), R6_STUB_SLEEP="120")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    launcher = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        t0 = time.time()
+        while len(list(tmp_path.glob("rank*.pid"))) < 2:
+            assert time.time() - t0 < 120 and launcher.poll() is None, "the stand-in ranks did not start"
+            time.sleep(0.2)
+        pids = [int(p.read_text()) for p in tmp_path.glob("rank*.pid")]
+        launcher.send_signal(signal.SIGKILL)
+        launcher.wait(timeout=30)
+
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                return False
+            try:     # a zombie whose parent has not reaped it yet counts as gone
+                return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+            except OSError:
+                return False
+
+        t0 = time.time()
+        while any(alive(p) for p in pids):
+            assert time.time() - t0 < 60, f"ranks {pids} outlived their launcher"
+            time.sleep(0.5)
+    finally:
+        if launcher.poll() is None:
+            launcher.kill()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
