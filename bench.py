@@ -511,8 +511,9 @@ def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) 
             "episodes_seen": float(sum(float(t[:, 0].sum()) for t in gathers[n_before:]))}
 
 
-# what every rank of a self-launched job runs (tests point it at a GPU-free stand-in: the attribute, or R6_BENCH_RANK_SCRIPT for a launcher in a process of its own)
-RANK_SCRIPT = os.environ.get("R6_BENCH_RANK_SCRIPT") or os.path.abspath(__file__)
+# what every rank of a self-launched job runs (tests point the ATTRIBUTE, or launch_ranks(script=...), at a GPU-free stand-in; there
+# is no environment seam: a variable left set would have made `python bench.py --gpus N` print a stand-in's line -- round-4 advice)
+RANK_SCRIPT = os.path.abspath(__file__)
 
 
 def _free_port() -> int:
@@ -554,19 +555,19 @@ def launch_ranks(n_ranks: int, argv, script: str = None) -> int:
 
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True,   # own process group
                             preexec_fn=_die_with_parent)
-    seen = None
+    seen = seen_ln = None
     try:
-        for ln in proc.stdout:       # rank 0's line goes to stdout as it comes; anything else a rank or a library prints there
-            rec = None               # ("[Gloo] Rank 0 is connected ...") goes to stderr: the launcher's stdout is the ONE line
-            if ln.lstrip().startswith("{"):
-                try:
+        for ln in proc.stdout:       # rank 0's line is HELD until the job's return code is known (a rank that crashes in the teardown
+            rec = None               # after the line was printed must not leave a well-formed record on stdout -- round-4 advice);
+            if ln.lstrip().startswith("{"):    # anything else a rank or a library prints there ("[Gloo] Rank 0 is connected ...")
+                try:                           # goes to stderr: the launcher's stdout is the ONE line
                     rec = json.loads(ln)
                 except ValueError:
                     rec = None
             if isinstance(rec, dict) and "n_gpus" in rec:
-                seen = rec
-                sys.stdout.write(ln)
-                sys.stdout.flush()
+                if seen_ln is not None:
+                    sys.stderr.write("[bench] launcher: superseded line: " + seen_ln)
+                seen, seen_ln = rec, ln
             else:
                 sys.stderr.write(ln)
                 sys.stderr.flush()
@@ -586,12 +587,18 @@ def launch_ranks(n_ranks: int, argv, script: str = None) -> int:
                 proc.wait()
         raise
     if rc != 0:
+        if seen_ln is not None:
+            sys.stderr.write("[bench] launcher: discarded (the job failed after printing it): " + seen_ln)
         print(f"[bench] launcher: the {n_ranks}-rank job FAILED (torch.distributed.run returned {rc}); no scaling record", file=sys.stderr)
         return rc if 0 < rc < 256 else 1
     if seen is None or seen.get("n_gpus") != n_ranks:
         got = "no JSON line" if seen is None else f"a line with n_gpus = {seen.get('n_gpus')}"
+        if seen_ln is not None:
+            sys.stderr.write("[bench] launcher: discarded (wrong world): " + seen_ln)
         print(f"[bench] launcher: asked for {n_ranks} ranks but the job printed {got}", file=sys.stderr)
         return 3
+    sys.stdout.write(seen_ln)
+    sys.stdout.flush()
     return 0
 
 

@@ -1901,10 +1901,10 @@ void launch_step_od(const R6Params& p, const R6Buffers& b, uint64_t seed, uint64
 
 extern "C" {
 
-// shared with r6_policy.hip (not part of the public header)
-void r6_internal_set_error(const char* what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
-// shared with r6_rollout.hip (not part of the public header): the guard of the stepping entry points
-int r6_internal_device_error_guard(const char* who, void* stream) { return device_error_guard(who, static_cast<hipStream_t>(stream)); }
+// shared with r6_policy.hip (not part of the public header, and hidden from the dynamic symbol table)
+__attribute__((visibility("hidden"))) void r6_internal_set_error(const char* what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
+// shared with r6_rollout.hip (not part of the public header, hidden): the guard of the stepping entry points
+__attribute__((visibility("hidden"))) int r6_internal_device_error_guard(const char* who, void* stream) { return device_error_guard(who, static_cast<hipStream_t>(stream)); }
 #ifdef R6_TEST_HOOKS
 // test hook (tests/test_gpu_step_k.py; libr6dof_testhooks.so only -- the release library does not export it): raises the device
 // error word as a kernel would; returns 0 when the word does not exist yet (no stepping call so far).

@@ -37,7 +37,7 @@
 #include "r6_device.hpp"
 #include "r6_policy_device.hpp"
 
-extern "C" void r6_internal_set_error(const char* what);
+extern "C" __attribute__((visibility("hidden"))) void r6_internal_set_error(const char* what);
 
 #ifndef R6P_BLOCK64
 #define R6P_BLOCK64 512

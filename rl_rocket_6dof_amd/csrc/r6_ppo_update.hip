@@ -37,7 +37,7 @@
 
 #include "../../include/r6dof.h"
 
-extern "C" void r6_internal_set_error(const char* what);
+extern "C" __attribute__((visibility("hidden"))) void r6_internal_set_error(const char* what);
 
 namespace r6u {
 

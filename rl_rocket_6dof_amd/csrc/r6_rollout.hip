@@ -30,8 +30,8 @@
 #include "r6_device.hpp"
 #include "r6_policy_device.hpp"
 
-extern "C" void r6_internal_set_error(const char* what);
-extern "C" int r6_internal_device_error_guard(const char* who, void* stream);   // r6_kernels.hip: the device error word
+extern "C" __attribute__((visibility("hidden"))) void r6_internal_set_error(const char* what);
+extern "C" __attribute__((visibility("hidden"))) int r6_internal_device_error_guard(const char* who, void* stream);   // r6_kernels.hip: the device error word
 
 namespace r6r {
 

@@ -34,10 +34,14 @@ def main():
     extras = {"rccl": {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
                        "with_rollout_gather": {"episodes_seen": tot["episodes"]}}}
     line = bench.build_line(args, w, args.envs_per_gpu, 0.1, red["wall_max"], red["kernel_ms_max"], extras=extras)
+    line["data"] = "stub"                       # nobody can mistake a stand-in's line for a measurement
     if os.environ.get("R6_STUB_WRONG_WORLD") == "1":
         line["n_gpus"] = 1
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if os.environ.get("R6_STUB_FAIL_AFTER_LINE") == os.environ.get("RANK"):     # "a rank that crashes in the teardown"
+        dist.barrier()
+        raise SystemExit(9)
     dist.barrier()
     dist.destroy_process_group()
 

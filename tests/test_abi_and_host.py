@@ -29,6 +29,15 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_lib.lib_path())
     for n in names:
         assert hasattr(lib, n), f"libr6dof.so does not export {n}"
+    # ... and nothing named r6_* beyond them: the cross-unit helpers (r6_internal_*) are hidden, the test hooks live in
+    # csrc/variants/libr6dof_testhooks.so only (round-4 review, Weak 9)
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("r6_")})
+    assert exported == names, f"exports not declared in include/r6dof.h: {sorted(set(exported) - set(names))}"
 
 
 def test_ctypes_mirrors_match_header_and_library():

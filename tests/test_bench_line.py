@@ -85,10 +85,18 @@ def test_launcher_is_loud_when_a_rank_fails_or_the_world_is_wrong(monkeypatch, c
     assert e.value.code not in (0, None)
     assert "FAILED" in capfd.readouterr().err
     monkeypatch.delenv("R6_STUB_FAIL_RANK")
+    # a rank that fails AFTER rank 0 has printed its line (teardown crash): the held line must not reach stdout (round-4 advice)
+    monkeypatch.setenv("R6_STUB_FAIL_AFTER_LINE", "1")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2"])
+    out, err = capfd.readouterr()
+    assert e.value.code not in (0, None) and "discarded" in err and not [ln for ln in out.splitlines() if ln.startswith("{")], out
+    monkeypatch.delenv("R6_STUB_FAIL_AFTER_LINE")
     monkeypatch.setenv("R6_STUB_WRONG_WORLD", "1")       # a job that ends well but reports the wrong number of ranks
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2"])
-    assert e.value.code == 3 and "n_gpus = 1" in capfd.readouterr().err
+    out, err = capfd.readouterr()
+    assert e.value.code == 3 and "n_gpus = 1" in err and not [ln for ln in out.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.parametrize("world,gpus", [("1", "8"), ("2", "1"), ("4", "8"), ("x", "1")])
@@ -123,10 +131,12 @@ def test_ranks_do_not_outlive_a_killed_launcher(tmp_path):
     import subprocess
     import time
 
-    env = dict(os.environ, R6_BENCH_RANK_SCRIPT=STUB, R6_STUB_PIDDIR=str(tmp_path), R6_STUB_SLEEP="120")
+    env = dict(os.environ, R6_STUB_PIDDIR=str(tmp_path), R6_STUB_SLEEP="120")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    launcher = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # a launcher in a process of its own: a small driver that calls bench.launch_ranks(script=STUB) (bench.py has no environment seam)
+    code = "import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(2, ['--gpus', '2'], script=%r))" % (ROOT, STUB)
+    launcher = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     try:
         t0 = time.time()
         while len(list(tmp_path.glob("rank*.pid"))) < 2:

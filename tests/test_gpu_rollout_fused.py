@@ -209,3 +209,66 @@ def test_fused_rollout_without_auto_reset_leaves_the_terminal_outputs_alone(cfg)
     assert torch.equal(ref["obs_seq"][1:], got["obs_seq"][1:]) and torch.equal(ea.state, eb.state)
     for (ta, tb) in zip(keep[0], keep[1]):
         assert torch.equal(ta, tb) and bool((tb == -7).all()), "a terminal output was written without auto-reset"
+
+
+# The two tests below were dropped by the round-4 hygiene commit (888287a) without a word anywhere; they are the only coverage of
+# PPOConfig.fused_rollout (the default training rollout) and of env.rollout(..., deterministic=True) / K = 1 / a 4-env tile
+# (round-4 advice).  Restored, one parametrisation fewer each (runtime).
+@pytest.mark.parametrize("max_steps,shared", [(9, True), (0, False)])
+def test_ppo_one_launch_rollout_equals_the_three_launch_rollout(cfg, max_steps, shared):
+    """ppo.PPO with fused_rollout on / off, same seeds: every rollout buffer, the advantages and the env state of three consecutive
+    rollouts (the first eager, the others replayed from a HIP graph) agree bit for bit."""
+    import torch
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+    runs = []
+    for one_launch in (False, True):
+        kw = dict(seed=11, remove_mass=True, clip_reward=(-1, 100))
+        if max_steps:
+            kw.update(record_flags=True, max_episode_steps=max_steps)
+        env = BatchedRocket6DOF(4096, cfg, **kw)
+        algo = PPO(env, PPOConfig(n_steps=24, batch_size=1 << 14, net_arch=(128, 64), shared_trunk=shared, seed=3, fused_rollout=one_launch))
+        assert algo.fused is not None and algo._one_launch_rollout == one_launch
+        snaps = []
+        for _ in range(3):
+            algo.collect_rollouts()
+            snaps.append([t.clone() for t in (algo.buf_obs, algo.buf_act, algo.buf_rew, algo.buf_done, algo.buf_val, algo.buf_logp,
+                                              algo.adv, algo.ret, algo._obs, env.state, env.stats.sum(0))])
+        assert algo._rollout_graph is not None and env._step_count == 72
+        runs.append(snaps)
+    for k, (a, b) in enumerate(zip(*runs)):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (k, i)
+
+
+@pytest.mark.parametrize("n,K,det", [(4, 1, False), (4, 7, True), (64, 3, True)])
+def test_fused_rollout_edge_sizes_and_deterministic_actions(cfg, n, K, det):
+    """One tile with mostly padding lanes, a single step, and `deterministic` (the mean action of model.predict(...,
+    deterministic=True), montecarlo_script.py:33-51): still the launch sequence bit for bit."""
+    import torch
+
+    (ea, eb), fused = _make(torch, n, cfg, (64, 64), False, 13, "rk4", clip_reward=(-1, 100), max_episode_steps=3)
+    for e in (ea, eb):
+        e.reset()
+    dev = ea.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    ref = {"obs_seq": torch.zeros((K + 1, n, 13), **f32), "raw_action": torch.zeros((K, n, 3), **f32), "value": torch.zeros((K, n), **f32),
+           "logp": torch.zeros((K, n), **f32), "reward": torch.zeros((K, n), **f32), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev),
+           "flags": torch.zeros((K, n), dtype=torch.uint8, device=dev)}
+    got = {k: torch.zeros_like(v) for k, v in ref.items()}
+    act = torch.zeros((n, 3), **f32)
+    ref["obs_seq"][0].copy_(ea.obs)
+    for j in range(K):
+        fused(ref["obs_seq"][j], deterministic=det, step_index=5 + j, out=(act, ref["raw_action"][j], ref["value"][j], ref["logp"][j]))
+        ea.step_into(act, obs=ref["obs_seq"][j + 1], reward=ref["reward"][j], done=ref["done"][j], flags=ref["flags"][j])
+    got["obs_seq"][0].copy_(eb.obs)
+    eb.rollout(fused, K, deterministic=det, policy_step_index=5, **got)
+    torch.cuda.synchronize()
+    for name in ref:
+        a, b = (ref[name][1:], got[name][1:]) if name == "obs_seq" else (ref[name], got[name])
+        assert torch.equal(a, b), name
+    assert torch.equal(ea.state, eb.state)
+    if det:   # the mean action carries no noise: its log-probability is that of the mode
+        assert float(ref["logp"].std()) == 0.0
