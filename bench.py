@@ -213,6 +213,14 @@ def parse_args(argv=None):
                     help="untimed auto-reset steps run once after reset(), before warmup: all envs start in lockstep, "
                          "so without it the timed region would sit on the first mass-termination wave instead of the "
                          "steady mix of flight phases")
+    ap.add_argument("--preroll-seconds", type=float, default=1.0,
+                    help="untimed stepping by TIME (not by count) after the burn-in and before --warmup: the chip's clocks and the "
+                         "launch pipeline are in their steady state when the contract's W + K steps run (2000 burn-in launches are "
+                         "75 ms; the first 30 ms of a process run 32 -> 53 -> 36 us per launch, gpurun_out/r5_trace_driver_shape_summary.json)")
+    ap.add_argument("--steady-launches", type=int, default=2000,
+                    help="launches of the `steady` record taken right AFTER the contract's timed region on the same env, in chunks of "
+                         "--steady-chunk launches (0 = skip): the distribution a K-launch sample is drawn from")
+    ap.add_argument("--steady-chunk", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the out_of_cache / configs1 side measurements (N = 1)")
@@ -355,7 +363,8 @@ def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: floa
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{n} envs/GPU x {world} GPU, {args.integrator} dt={dt} fp32, {args.variant} "
-                               f"Rocket6DOF.step, random actions, auto-reset, {args.burnin} burn-in steps, "
+                               f"Rocket6DOF.step, random actions, auto-reset, {args.burnin} burn-in steps + {args.preroll_seconds:g} s of "
+                               f"untimed stepping before the {args.warmup} warm-up and {args.steps} timed steps, "
                                f"{args.k} env step(s) per launch",
                    "envs_total": total, "integrator": args.integrator, "dt": dt, "variant": args.variant,
                    "steps_per_launch": args.k, "bytes_per_env_step": bytes_per, "parallelism": f"env-shard x{world}",
@@ -401,6 +410,51 @@ def make_pool(torch, n, k, count, dev, seed):
     return [(torch.rand(shape, generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(count)]
 
 
+def preroll(env, pool, seconds: float, k: int, sync) -> int:
+    """Untimed stepping for `seconds` of wall time (launches in batches of 200 with a synchronize between them); returns the
+    number of env steps issued."""
+    done, npool = 0, len(pool)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        if k <= 1:
+            for j in range(200):
+                env.step_async(pool[j % npool])
+            done += 200
+        else:
+            for j in range(max(1, 200 // k)):
+                env.step_k(pool[j % npool], out=env._bench_out)
+            done += max(1, 200 // k) * k
+        sync()
+    return done
+
+
+def steady_record(env, pool, launches: int, chunk: int, k: int, stream, torch, sync) -> dict:
+    """`launches` back-to-back launches on the same env right after the contract's timed region, HIP events between chunks of
+    `chunk` launches: the distribution of CHUNK MEANS (us per env step) a `chunk`-launch timed region is a sample of.  Slow
+    episodes (1.5-3 ms at +5 ... +15 %, arriving every 8-25 ms, not replaying with the data: DESIGN.md section 6) show as the
+    distance between p90 / max and the median."""
+    chunks = max(1, launches // chunk)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(chunks + 1)]
+    npool = len(pool)
+    per_launch = max(k, 1)
+    sync()
+    ev[0].record(stream)
+    for c in range(chunks):
+        for j in range(chunk):
+            if k <= 1:
+                env.step_async(pool[j % npool])
+            else:
+                env.step_k(pool[j % npool], out=env._bench_out)
+        ev[c + 1].record(stream)
+    sync()
+    us = sorted(ev[c].elapsed_time(ev[c + 1]) / (chunk * per_launch) * 1e3 for c in range(chunks))
+    q = lambda f: us[min(chunks - 1, int(f * chunks))]
+    med = q(0.5)
+    return {"launches": chunks * chunk, "chunk_launches": chunk, "chunks": chunks, "unit": "us per env step, HIP events, chunk means",
+            "mean": sum(us) / chunks, "median": med, "p10": q(0.1), "p90": q(0.9), "min": us[0], "max": us[-1],
+            "share_of_chunks_above_1.06_x_median": sum(1 for x in us if x > 1.06 * med) / chunks}
+
+
 def side_measurement(torch, dev, cfg, *, n, integrator, dt, k, pool_count, burnin, steps, warmup, label):
     """One secondary workload timed in the same run (N = 1): returns a dict with its own algorithmic-bytes figure."""
     from rl_rocket_6dof_amd import BatchedRocket6DOF
@@ -434,6 +488,49 @@ def side_measurement(torch, dev, cfg, *, n, integrator, dt, k, pool_count, burni
         out["frac"] = ach / HBM_PEAK_GBS
     del env, pool
     torch.cuda.empty_cache()
+    return out
+
+
+def two_groups_side_measurement(torch, dev, cfg, rounds: int = 9, steps: int = 400) -> dict:
+    """The headline workload stepped as TWO env groups of 2^19 envs, one r6_step launch each on two streams the env owns
+    (BatchedRocket6DOF(groups=2, group_sync="none"): two independent pipelines, as an asynchronous vector env with one policy call
+    per group drives them) against ONE launch per step -- on the same buffers, in alternating rounds of `steps` steps, wall clock
+    between synchronisations.  A labelled side figure, never the line's `value`: the headline stays one launch per step."""
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n = 1 << 20
+    out = {"workload": "2^20 envs, RK4 dt 0.1, raw step, as two groups of 2^19 envs on two streams (no per-step fork / join) vs one launch per step; "
+                       f"same buffers, {rounds} alternating rounds of {steps} steps, wall clock"}
+    try:
+        env = BatchedRocket6DOF(n, cfg, device=dev, groups=2, group_sync="none", auto_reset=True, record_flags=False, record_terms=False,
+                                track_episodes=False, seed=42)
+        pool = make_pool(torch, n, 1, 2, dev, 977)
+        env.reset()
+        torch.cuda.synchronize(dev)
+        for j in range(2000):
+            env.step_async(pool[j % 2])
+        env.join_groups()
+        res = {1: [], 2: []}
+        for r in range(rounds):
+            for g in ((1, 2) if r % 2 == 0 else (2, 1)):
+                env.groups = g                    # the same env, the same memory: only the number of launches per step changes
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for j in range(steps):
+                    env.step_async(pool[j % 2])
+                env.join_groups()
+                torch.cuda.synchronize(dev)
+                res[g].append((time.perf_counter() - t0) / steps * 1e6)
+        env.groups = 2
+        med = lambda v: sorted(v)[len(v) // 2]
+        one, two = med(res[1]), med(res[2])
+        out.update({"one_launch_us_per_step": one, "two_groups_us_per_step": two, "gain_us": one - two,
+                    "two_groups_env_steps_per_s": n / (two * 1e-6), "rounds_one": res[1], "rounds_two": res[2],
+                    "frac_of_hbm_peak_two_groups": BYTES_RAW * n / (two * 1e-6) / 1e9 / HBM_PEAK_GBS})
+        del env, pool
+        torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001 -- a side figure must not cost the line
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
     return out
 
 
@@ -714,10 +811,22 @@ def main(argv=None):
         torch.cuda.synchronize(dev)
 
     stream = torch.cuda.current_stream(dev)
+    if args.preroll_seconds > 0:
+        preroll(env, pool, args.preroll_seconds, args.k, lambda: torch.cuda.synchronize(dev))     # untimed, by time
     timed_loop(env, pool, max(args.warmup, args.k), args.k, barrier, stream, torch)        # W untimed steps
     wall, kernel_ms = timed_loop(env, pool, args.steps, args.k, barrier, stream, torch)    # EXACTLY K timed steps
 
     extras = {}
+    if args.steady_launches > 0:
+        # the distribution the timed region above was drawn from, same env, same process, right behind it (every rank takes it:
+        # the ranks stay in step; the line carries rank 0's)
+        st = steady_record(env, pool, args.steady_launches, args.steady_chunk, args.k, stream, torch, lambda: torch.cuda.synchronize(dev))
+        st["timed_region_kernel_us"] = kernel_ms * 1e3
+        st["timed_region_over_median"] = kernel_ms * 1e3 / st["median"]
+        st["note"] = ("the contract's timed region is ONE sample of --steps launches; at --steps 20 it is 0.8 ms long, shorter than a slow "
+                      "episode of the chip, so its value moves within [min, max] of these chunk means from run to run; wall-clock "
+                      "ms_per_step adds the start-up of the first launch after the barrier and the host's wake-up (~1.7 us per step at 20 steps)")
+        extras["steady"] = st
     if multi:
         rccl_live[0] = True
         red = r6dist.reduce_bench_times(wall, kernel_ms, device=dev)
@@ -770,6 +879,7 @@ def main(argv=None):
                 torch, dev, cfg, n=1 << 20, integrator="rk45", dt=None, k=1, pool_count=2, burnin=600, steps=200, warmup=40,
                 label="2^20 envs, in-kernel adaptive RK45 (scipy's step control, the reference's own integrator: simulator.py:83-88), dt 0.1, raw step: "
                       "bound by arithmetic (8-20 RHS evaluations per env step, the wave follows its slowest lane), not by HBM")
+            extras["two_groups"] = two_groups_side_measurement(torch, dev, cfg)
             extras["ppo_training"] = ppo_side_measurement(torch, dev)
         if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:
             extras["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -164,8 +164,9 @@ int r6_clear_device_error(void);
  * "even_xcd_share" (share of the tiles given to the workgroups on even XCDs, < 0 = default), "grid_blocks" (> 0 pins the
  * persistent grid), "sweep" (tile order on odd steps, -1 = default), "sweep_flags" (4: no wave-priority ladder),
  * "balanced_tiles_per_wave" (large shards: tiles per wave of the dispatcher-balanced grid, 0 = by shard size), "streaming_stores"
- * (non-temporal output stores: -1 = by shard size, 0 = never, 1 = always).  The first three are also read once from the environment:
- * R6_EVEN_XCD_SHARE, R6_GRID_BLOCKS, R6_SWEEP. */
+ * (non-temporal output stores: -1 = by shard size, 0 = never, 1 = always), "rk45_defer" (integrator R6_RK45: a wave hands its last
+ * <= this many unfinished lanes to the workgroup's straggler pass instead of following them; 0 = never; R6_RK45_DEFER).  The first
+ * three are also read once from the environment: R6_EVEN_XCD_SHARE, R6_GRID_BLOCKS, R6_SWEEP. */
 int r6_tune(const char *key, double value);
 
 /* Rocket6DOF.step for n envs (rocket_env.py:201-231): denormalise action, integrate one env

@@ -143,9 +143,23 @@ class BatchedRocket6DOF(VecEnv):
                  auto_reset: bool = True, seed: Optional[int] = None, env_offset: int = 0,
                  record_terms: bool = False, record_flags: bool = True, track_episodes: bool = True,
                  numpy_io: bool = False, lib_path: Optional[str] = None, reward_annealing: bool = False,
-                 vertical_attitude_reward=None, record_nfev: bool = False):
+                 vertical_attitude_reward=None, record_nfev: bool = False, groups: int = 1, group_sync: str = "caller"):
+        """``groups`` > 1 (round 5): ``step_async`` steps the batch as that many contiguous env groups, each with its own ``r6_step``
+        launch on a stream the env owns -- launches of ONE stream serialise, launches of two streams overlap, and one group's
+        ramp (first loads) and tail (last tiles, reset drain) then run under the other group's bulk.  Results do not depend on
+        it: envs are independent and the reset RNG is keyed by the global env index (the sharding invariance of section 5 of
+        DESIGN.md, one level down).  ``group_sync``: "caller" -- every ``step_async`` makes the group streams wait for the
+        caller's current stream (the actions are ready) and ``step_wait`` makes the caller's stream wait for the groups: safe
+        anywhere, two event records and four stream waits per step; "none" -- no ordering against the caller's stream at all:
+        the groups are independent pipelines (what an asynchronous vector env with one policy call per group does);
+        ``join_groups()`` orders the caller's stream behind them on request.  reset / step_k / rollout / set_state always join."""
         if num_envs < 1:
             raise ValueError("num_envs must be >= 1")
+        if group_sync not in ("caller", "none"):
+            raise ValueError("group_sync must be 'caller' or 'none'")
+        self.groups, self.group_sync = int(groups), group_sync
+        if self.groups < 1 or (self.groups > 1 and num_envs < 128 * self.groups):
+            raise ValueError("groups must be >= 1 and every group needs at least two 64-env tiles")
         self.lib = _lib.load(lib_path)   # raises if the HIP extension is missing -- no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedRocket6DOF needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -193,9 +207,17 @@ class BatchedRocket6DOF(VecEnv):
         self.ep_return = torch.zeros((n,), **f32) if track else None
         self.fin_return = torch.zeros((n,), **f32) if (track and auto_reset) else None
         self.fin_length = torch.zeros((n,), dtype=torch.int32, device=dev) if (track and auto_reset) else None
-        self.stats = torch.zeros((MAX_BLOCKS, NUM_STATS), dtype=torch.float64, device=dev) if track else None   # float64: counts stay exact
+        # float64: counts stay exact.  One block of MAX_BLOCKS per-workgroup rows per env group: concurrent launches never share a row
+        self.stats = torch.zeros((MAX_BLOCKS * self.groups, NUM_STATS), dtype=torch.float64, device=dev) if track else None
+        # group g = envs [bounds[g], bounds[g + 1]): cut at multiples of 64 (tile-aligned rows, 16-byte aligned action / obs blocks)
+        self._group_bounds = [min(n, (n * g // self.groups + 32) // 64 * 64) for g in range(self.groups)] + [n]
+        self._group_streams = [torch.cuda.Stream(device=dev) for _ in range(self.groups)] if self.groups > 1 else []
+        self._fork_event = torch.cuda.Event() if self.groups > 1 else None
+        self._join_events = [torch.cuda.Event() for _ in range(self.groups)] if self.groups > 1 else []
+        self._groups_in_flight = False
 
         self._buf = R6Buffers()
+        self._gbufs = []
         self._step_base = None
         self._fill_buffers(self._act)
         self._step_count = 0     # global step counter (keys the auto-reset RNG), first step = 1
@@ -213,6 +235,8 @@ class BatchedRocket6DOF(VecEnv):
         b.ep_step, b.ep_return = _ptr(self.ep_step), _ptr(self.ep_return)
         b.fin_return, b.fin_length, b.stats = _ptr(self.fin_return), _ptr(self.fin_length), _ptr(self.stats)
         b.nfev = _ptr(self.nfev)
+        if self.groups > 1 and hasattr(self, "_group_bounds"):
+            self._gbufs = [self._group_buffers(b, g) for g in range(self.groups)]   # per-step work: only their action pointers move
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -231,6 +255,7 @@ class BatchedRocket6DOF(VecEnv):
     def reset(self, mask: Optional[torch.Tensor] = None):
         """rocket_env.py:180-199 for every env (or those with mask != 0): sample the initial
         condition from U(IC - ICRange/2, IC + ICRange/2), normalise the quaternion, new episode."""
+        self.join_groups()
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
@@ -245,6 +270,35 @@ class BatchedRocket6DOF(VecEnv):
             torch.cuda.current_stream(self.device).synchronize()  # keep `m` alive until consumed
         return self._out(self.obs)
 
+    def _group_buffers(self, b: R6Buffers, g: int) -> R6Buffers:
+        """The R6Buffers of env group g: every pointer moved to the group's first env (SoA rows keep their pitch ``ld``), its
+        own block of statistics rows."""
+        a0, a1 = self._group_bounds[g], self._group_bounds[g + 1]
+        od = self.obs_dim
+        gb = R6Buffers.from_buffer_copy(b)
+        gb.n = a1 - a0
+
+        def mv(name, bytes_per_env):
+            v = getattr(b, name)
+            if v:
+                setattr(gb, name, C.c_void_p(v + a0 * bytes_per_env))
+
+        for name, w in (("state", 4), ("epconst", 4), ("action", 4 * ACTION_DIM), ("obs", 4 * od), ("reward", 4), ("done", 1), ("flags", 1),
+                        ("terms", 4), ("final_obs", 4 * od), ("ep_step", 4), ("ep_return", 4), ("fin_return", 4), ("fin_length", 4), ("nfev", 1)):
+            mv(name, w)
+        if b.stats:
+            gb.stats = C.c_void_p(b.stats + g * MAX_BLOCKS * NUM_STATS * 8)
+        return gb
+
+    def join_groups(self) -> None:
+        """groups > 1: the caller's current stream waits for everything the group streams have been given so far."""
+        if self._groups_in_flight:
+            cur = torch.cuda.current_stream(self.device)
+            for ev, st in zip(self._join_events, self._group_streams):
+                ev.record(st)
+                cur.wait_event(ev)
+            self._groups_in_flight = False
+
     def step_async(self, actions) -> None:
         if torch.is_tensor(actions) and actions.device == self.device and actions.dtype == torch.float32 \
                 and actions.is_contiguous() and actions.data_ptr() % 16 == 0:
@@ -257,9 +311,23 @@ class BatchedRocket6DOF(VecEnv):
         self._buf.action = _ptr(a)
         self._step_count += 1
         with torch.cuda.device(self.device):
-            rc = self.lib.r6_step(C.byref(self.params), C.byref(self._buf), self._seed, self._step_count,
-                                  self.env_offset, self._stream())
-        _lib.check(rc, "r6_step", self.lib)
+            if self.groups == 1:
+                rc = self.lib.r6_step(C.byref(self.params), C.byref(self._buf), self._seed, self._step_count,
+                                      self.env_offset, self._stream())
+                _lib.check(rc, "r6_step", self.lib)
+            else:
+                if self.group_sync == "caller":     # fork: the groups start behind whatever the caller's stream holds (the actions)
+                    self._fork_event.record(torch.cuda.current_stream(self.device))
+                for g, st in enumerate(self._group_streams):
+                    if self.group_sync == "caller":
+                        st.wait_event(self._fork_event)
+                    gb = self._gbufs[g]
+                    gb.action = a.data_ptr() + self._group_bounds[g] * 4 * ACTION_DIM
+                    gb.step_base = self._buf.step_base
+                    rc = self.lib.r6_step(C.byref(self.params), C.byref(gb), self._seed, self._step_count,
+                                          self.env_offset + self._group_bounds[g], C.c_void_p(st.cuda_stream))
+                    _lib.check(rc, "r6_step", self.lib)
+                self._groups_in_flight = True
         self._pending = a   # keeps the action tensor alive until step_wait
 
     def set_step_base(self, base: Optional[torch.Tensor]) -> None:
@@ -280,6 +348,7 @@ class BatchedRocket6DOF(VecEnv):
         loop, and nothing but the launch itself when the loop is recorded into a HIP graph.  Outputs that are not given
         go to the env's buffers as in ``step``.  ``done`` / ``flags``: uint8; every tensor contiguous on the env's device,
         ``obs`` / ``final_obs`` 16-byte aligned.  Device tensors in, nothing returned, no ``infos``."""
+        self.join_groups()
         n, od = self.num_envs, self.obs_dim
         if not (torch.is_tensor(actions) and actions.device == self.device and actions.dtype == torch.float32
                 and actions.is_contiguous() and tuple(actions.shape) == (n, ACTION_DIM) and actions.data_ptr() % 16 == 0):
@@ -314,6 +383,8 @@ class BatchedRocket6DOF(VecEnv):
         _lib.check(rc, "r6_step", self.lib)
 
     def step_wait(self):
+        if self.groups > 1 and self.group_sync == "caller":
+            self.join_groups()
         self._pending = None
         done = self.done.view(torch.bool)
         return self._out(self.obs), self._out(self.reward), self._out(done), LazyInfos(self)
@@ -333,6 +404,7 @@ class BatchedRocket6DOF(VecEnv):
         ``step`` calls.  ``last_only=True`` keeps just the last step's outputs (in the env's own single-step buffers:
         ``env.obs`` ...) and stores nothing for the earlier ones.  ``out`` recycles a dict returned by an earlier call
         with the same K."""
+        self.join_groups()
         a = actions
         if not (torch.is_tensor(a) and a.device == self.device and a.dtype == torch.float32 and a.is_contiguous()
                 and a.dim() == 3 and tuple(a.shape[1:]) == (self.num_envs, ACTION_DIM) and a.data_ptr() % 16 == 0):
@@ -391,6 +463,7 @@ class BatchedRocket6DOF(VecEnv):
         and optionally ``obs_seq`` (k + 1, N, obs_dim) (row j + 1 <- the observation after step j; row 0 is left alone),
         ``raw_action`` (k, N, 3), ``value`` / ``logp`` (k, N), ``flags`` (k, N) uint8, ``boot_value`` (k, N) (written only where a
         step truncated an env).  ``env.obs`` receives the observation after the last step."""
+        self.join_groups()
         n, od, dev = self.num_envs, self.obs_dim, self.device
         if policy.obs_dim != od or policy.device != dev:
             raise ValueError("policy and env disagree on obs_dim / device")
@@ -426,11 +499,13 @@ class BatchedRocket6DOF(VecEnv):
     # ------------------------------------------------------------------------------------------
     def get_state(self) -> torch.Tensor:
         """(N,14) copy of the simulator states (rocket_env.py:623)."""
+        self.join_groups()
         return self.state[:, : self.num_envs].t().contiguous()
 
     def set_state(self, states, m0=None, v0=None):
         """Loads explicit simulator states (N,14); m0 defaults to the state's mass (a fresh
         Simulator6DOF, simulator.py:42), v0 to its speed (rocket_env.py:649-651)."""
+        self.join_groups()
         s = torch.as_tensor(states, dtype=torch.float32, device=self.device).reshape(self.num_envs, STATE_DIM)
         self.state[:, : self.num_envs] = s.t()
         self.epconst[0, : self.num_envs] = s[:, 13] if m0 is None else torch.as_tensor(m0, dtype=torch.float32, device=self.device)
@@ -469,6 +544,7 @@ class BatchedRocket6DOF(VecEnv):
         (stream-ordered: one reduction kernel and, with ``clear``, one fill)."""
         if self.stats is None:
             raise RuntimeError("episode tracking is disabled (track_episodes=False)")
+        self.join_groups()
         s = self.stats.sum(0)
         if clear:
             self.stats.zero_()
@@ -479,6 +555,7 @@ class BatchedRocket6DOF(VecEnv):
         float64 on the host)."""
         if self.stats is None:
             raise RuntimeError("episode tracking is disabled (track_episodes=False)")
+        self.join_groups()
         s = self.stats.sum(0).cpu().numpy()
         if clear:
             self.stats.zero_()

@@ -545,44 +545,48 @@ constexpr Derived T = make_derived();
 __device__ __forceinline__ constexpr int comp(int d) { return d < 7 ? 3 + d : 4 + d; }   // 3,4,5 | 6,7,8,9 | 11,12
 }  // namespace dp45
 
-// One env step [0, dt] of the adaptive integrator.  Returns status (0 reached dt, 1 ground event,
-// -1 step size underflow -- the reference folds any non-zero status into done, env:213).
-// nfev receives the number of RHS evaluations (scipy's sol.nfev).
-__device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J, float dt,
-                                              int& nfev) {
+// What one lane carries from attempt to attempt of the adaptive integrator (next to its state y and the control of the step):
+// enough to stop after any attempt and resume later, in another wave (step_kernel's straggler pass).
+struct Rk45Lane {
+    float K0[dp45::D];   // f(y) of the step in progress (FSAL: f(y_new) of the step before)
+    float t, h_abs;      // time reached within [0, dt]; step size the next attempt starts from
+    int nfev;            // RHS evaluations so far (scipy's sol.nfev)
+    int status;          // 0 integrating, 1 ground event, -1 step size underflow
+    int tries;           // rejected attempts of the step in progress (scipy's step_rejected <=> tries > 0)
+    int steps;           // accepted steps
+};
+__device__ __forceinline__ bool rk45_active(const Rk45Lane& L, float dt) { return L.status == 0 && L.t < dt && L.steps < 4096; }
+
+// the force / torque / kinematics part of the RHS at state `ya` (only ya[0], ya[3..12] are read), into a stage vector
+__device__ __forceinline__ void rk45_eval(const float (&ya)[kDyn], float im, const Control& c, const Inertia& J, float (&k)[dp45::D]) {
+    float dv[3], dw[2], dq[4];
+    rhs_dyn(ya, im, c, J, dv, dw);
+    rhs_quat(ya, dq);
+    k[0] = dv[0];
+    k[1] = dv[1];
+    k[2] = dv[2];
+    k[3] = dq[0];
+    k[4] = dq[1];
+    k[5] = dq[2];
+    k[6] = dq[3];
+    k[7] = dw[0];
+    k[8] = dw[1];
+}
+
+// f(y) and select_initial_step (scipy _ivp/common.py): two RHS evaluations.
+__device__ __forceinline__ void rk45_begin(const float (&y)[kDyn], float mass, const Control& c, const Inertia& J, float dt, Rk45Lane& L) {
     using namespace dp45;
-    float K[6][D];    // stages 1..6 of the step in progress; K[0] = f(y) (FSAL: f(y_new) of the step before)
-    float Kn[D];      // f(y_new)
-    float ynew[kDyn];
     const float mdot = c.mdot;
     auto sq = [](float v) { return v * v; };
-    // the force / torque / kinematics part of the RHS at state `ya` (only ya[0], ya[3..12] are read), into a stage vector
-    auto eval = [&](const float (&ya)[kDyn], float im, float (&k)[D]) __attribute__((always_inline)) {
-        float dv[3], dw[2], dq[4];
-        rhs_dyn(ya, im, c, J, dv, dw);
-        rhs_quat(ya, dq);
-        k[0] = dv[0];
-        k[1] = dv[1];
-        k[2] = dv[2];
-        k[3] = dq[0];
-        k[4] = dq[1];
-        k[5] = dq[2];
-        k[6] = dq[3];
-        k[7] = dw[0];
-        k[8] = dw[1];
-    };
-
-    eval(y, frcp(mass), K[0]);
-    nfev = 1;
-    // ---- select_initial_step (common.py) --------------------------------------------------------------
-    float h_abs;
+    float Kn[D], ynew[kDyn];
+    rk45_eval(y, frcp(mass), c, J, L.K0);
     {
         float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < kDyn; ++i) {   // the 13 dynamic components: derivative = v for r, K[0] for v / q / omega_yz, 0 for omega_x
+        for (int i = 0; i < kDyn; ++i) {   // the 13 dynamic components: derivative = v for r, K0 for v / q / omega_yz, 0 for omega_x
             const float isc = frcp(fmaf(fabsf(y[i]), kRtol, kAtol));
             d0 += sq(y[i] * isc);
-            const float f0 = (i < 3) ? y[3 + i] : ((i == 10) ? 0.0f : K[0][i < 10 ? i - 3 : i - 4]);
+            const float f0 = (i < 3) ? y[3 + i] : ((i == 10) ? 0.0f : L.K0[i < 10 ? i - 3 : i - 4]);
             d1 += sq(f0 * isc);
         }
         const float iscm = frcp(fmaf(fabsf(mass), kRtol, kAtol));
@@ -595,168 +599,193 @@ __device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, con
 #pragma unroll
         for (int i = 0; i < 3; ++i) ynew[i] = fmaf(h0, y[3 + i], y[i]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) ynew[comp(d)] = fmaf(h0, K[0][d], y[comp(d)]);
+        for (int d = 0; d < D; ++d) ynew[comp(d)] = fmaf(h0, L.K0[d], y[comp(d)]);
         ynew[10] = y[10];
-        eval(ynew, frcp(fmaf(-mdot, h0, mass)), Kn);
-        nfev = 2;
+        rk45_eval(ynew, frcp(fmaf(-mdot, h0, mass)), c, J, Kn);
         float d2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) d2 += sq((ynew[3 + i] - y[3 + i]) * frcp(fmaf(fabsf(y[i]), kRtol, kAtol)));   // f1 - f0 of the position rows
 #pragma unroll
-        for (int d = 0; d < D; ++d) d2 += sq((Kn[d] - K[0][d]) * frcp(fmaf(fabsf(y[comp(d)]), kRtol, kAtol)));
+        for (int d = 0; d < D; ++d) d2 += sq((Kn[d] - L.K0[d]) * frcp(fmaf(fabsf(y[comp(d)]), kRtol, kAtol)));
         d2 = fsqrt(d2 * (1.0f / 14.0f)) * frcp(h0);
         const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : fexp2(0.2f * flog2(0.01f * frcp(fmaxf(d1, d2))));
-        h_abs = fminf(fminf(100.0f * h0, h1), dt);
+        L.h_abs = fminf(fminf(100.0f * h0, h1), dt);
     }
+    L.t = 0.0f;
+    L.nfev = 2;
+    L.status = 0;
+    L.tries = 0;
+    L.steps = 0;
+}
 
-    float t = 0.0f;
-    int status = 0;
-#pragma unroll 1
-    for (int guard = 0; guard < 4096 && status == 0 && t < dt; ++guard) {
-        const float min_step = 1e-6f * dt;   // fp32 stand-in for scipy's 10 ulp(t)
-        h_abs = fmaxf(h_abs, min_step);
-        bool rejected = false, accepted = false;
-        float h = 0.0f;
-#pragma unroll 1
-        for (int tries = 0; tries < 64 && !accepted; ++tries) {
-            if (h_abs < min_step) {
-                status = -1;
-                break;
-            }
-            h = fminf(h_abs, dt - t);
-            h_abs = h;
-            const float hh = h * h;
-            // ---- rk_step (rk.py): stages 1..5, y_new, f_new --------------------------------------------
-#pragma unroll
-            for (int st = 1; st < 6; ++st) {
-                float ys[kDyn];
-                {   // altitude (the only position the forces read): x + h C v_x + h^2 sum_m AA[st][m] Kv_x[m]
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int m = 0; m + 1 < st; ++m) acc = fmaf(T.AA[st][m], K[m][0], acc);
-                    ys[0] = fmaf(hh, acc, fmaf(h * C[st], y[3], y[0]));
-                    ys[1] = ys[2] = 0.0f;   // never read
-                }
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < st; ++j) acc = fmaf(A[st][j], K[j][d], acc);
-                    ys[comp(d)] = fmaf(h, acc, y[comp(d)]);
-                }
-                ys[10] = y[10];
-                eval(ys, frcp(fmaf(-mdot, t + C[st] * h, mass)), K[st]);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int m = 0; m < 5; ++m) acc = fmaf(T.BA[m], K[m][i], acc);
-                ynew[i] = fmaf(hh, acc, fmaf(h, y[3 + i], y[i]));
-            }
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc = fmaf(B[j], K[j][d], acc);
-                ynew[comp(d)] = fmaf(h, acc, y[comp(d)]);
-            }
-            ynew[10] = y[10];
-            eval(ynew, frcp(fmaf(-mdot, t + h, mass)), Kn);
-            nfev += 6;
-            // ---- error norm ------------------------------------------------------------------------------
-            float en = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {   // position rows: h^2 sum_m EA[m] Kv[m]
-                float e = 0.0f;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) e = fmaf(T.EA[m], K[m][i], e);
-                const float sc = fmaf(fmaxf(fabsf(y[i]), fabsf(ynew[i])), kRtol, kAtol);
-                en += sq(e * hh * frcp(sc));
-            }
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float e = E[6] * Kn[d];
-#pragma unroll
-                for (int j = 5; j >= 0; --j) e = fmaf(E[j], K[j][d], e);
-                const float sc = fmaf(fmaxf(fabsf(y[comp(d)]), fabsf(ynew[comp(d)])), kRtol, kAtol);
-                en += sq(e * h * frcp(sc));
-            }
-            // en = error_norm^2 (omega_x and the mass contribute 0 to the sum, 1 each to the count); norm < 1 <=> en < 1, and
-            // norm^-1/5 = en^-1/10 = exp2(-0.1 log2 en)  (en == 0: exp2(+inf) = inf, cut to kMaxFactor like scipy's special case)
-            en *= (1.0f / 14.0f);
-            const float pw = kSafety * fexp2(-0.1f * flog2(en));
-            if (en < 1.0f) {
-                float factor = fminf(kMaxFactor, pw);
-                if (rejected) factor = fminf(1.0f, factor);
-                h_abs *= factor;
-                accepted = true;
-            } else {
-                h_abs *= fmaxf(kMinFactor, pw);
-                rejected = true;
-            }
-        }
-        if (!accepted) {
-            if (status == 0) status = -1;
-            break;
-        }
-        // ---- terminal event on the accepted sub-step (ivp.py find_active_events / handle_events) ---------
-        if (crossing(y[0], ynew[0])) {
-            // y(s) = y_old + h s (Q0 + Q1 s + Q2 s^2 + Q3 s^3), Q = K^T P; position rows through PS / PA (see Derived)
-            auto q_pos = [&](int i, float (&qq)[4]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) acc = fmaf(T.PA[m][k], K[m][i], acc);
-                    qq[k] = fmaf(h, acc, T.PS[k] * y[3 + i]);
-                }
-            };
-            float q[4];
-            q_pos(0, q);
-            const float cx[5] = {y[0], h * q[0], h * q[1], h * q[2], h * q[3]};
-            const float th = poly_root01(cx, y[0], ynew[0]);
-            float yev[kDyn];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float qq[4];
-                q_pos(i, qq);
-                yev[i] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[i]);
-            }
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                float qq[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) qq[k] = fmaf(K[j][d], P[j][k], qq[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) qq[k] = fmaf(Kn[d], P[6][k], qq[k]);
-                yev[comp(d)] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[comp(d)]);
-            }
-#pragma unroll
-            for (int i = 0; i < kDyn; ++i) {
-                if (i != 10) y[i] = yev[i];
-            }
-            t += th * h;
-            status = 1;
-        } else {
-#pragma unroll
-            for (int i = 0; i < kDyn; ++i) y[i] = ynew[i];
-#pragma unroll
-            for (int d = 0; d < D; ++d) K[0][d] = Kn[d];   // FSAL
-            t += h;
-        }
+// ONE attempt of a step (rk.py _step_impl: rk_step, error norm, accept / reject, next step size) and, when it was accepted, the
+// terminal-event check on it (ivp.py find_active_events / handle_events).  The caller guarantees rk45_active(L).  `mass0` is the
+// mass at t = 0 (the mass is linear in time: it is advanced analytically).  The loop  while (rk45_active) rk45_attempt  is,
+// operation for operation, scipy's nested loop (steps x tries) of one lane.
+__device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, const Control& c, const Inertia& J, float dt, Rk45Lane& L) {
+    using namespace dp45;
+    const float mdot = c.mdot;
+    auto sq = [](float v) { return v * v; };
+    float K[6][D];    // stages 1..6 of the attempt; K[0] = L.K0
+    float Kn[D];      // f(y_new)
+    float ynew[kDyn];
+    const float min_step = 1e-6f * dt;   // fp32 stand-in for scipy's 10 ulp(t)
+    if (L.tries == 0) L.h_abs = fmaxf(L.h_abs, min_step);   // a new step starts
+    if (L.h_abs < min_step || L.tries >= 64) {
+        L.status = -1;
+        return;
     }
-    mass = fmaf(-mdot, t, mass);
+    const float t = L.t;
+    const float h = fminf(L.h_abs, dt - t);
+    L.h_abs = h;
+    const float hh = h * h;
+#pragma unroll
+    for (int d = 0; d < D; ++d) K[0][d] = L.K0[d];
+    // ---- rk_step (rk.py): stages 1..5, y_new, f_new --------------------------------------------
+#pragma unroll
+    for (int st = 1; st < 6; ++st) {
+        float ys[kDyn];
+        {   // altitude (the only position the forces read): x + h C v_x + h^2 sum_m AA[st][m] Kv_x[m]
+            float acc = 0.0f;
+#pragma unroll
+            for (int m = 0; m + 1 < st; ++m) acc = fmaf(T.AA[st][m], K[m][0], acc);
+            ys[0] = fmaf(hh, acc, fmaf(h * C[st], y[3], y[0]));
+            ys[1] = ys[2] = 0.0f;   // never read
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < st; ++j) acc = fmaf(A[st][j], K[j][d], acc);
+            ys[comp(d)] = fmaf(h, acc, y[comp(d)]);
+        }
+        ys[10] = y[10];
+        rk45_eval(ys, frcp(fmaf(-mdot, t + C[st] * h, mass0)), c, J, K[st]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc = fmaf(T.BA[m], K[m][i], acc);
+        ynew[i] = fmaf(hh, acc, fmaf(h, y[3 + i], y[i]));
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc = fmaf(B[j], K[j][d], acc);
+        ynew[comp(d)] = fmaf(h, acc, y[comp(d)]);
+    }
+    ynew[10] = y[10];
+    rk45_eval(ynew, frcp(fmaf(-mdot, t + h, mass0)), c, J, Kn);
+    L.nfev += 6;
+    // ---- error norm ------------------------------------------------------------------------------
+    float en = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {   // position rows: h^2 sum_m EA[m] Kv[m]
+        float e = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) e = fmaf(T.EA[m], K[m][i], e);
+        const float sc = fmaf(fmaxf(fabsf(y[i]), fabsf(ynew[i])), kRtol, kAtol);
+        en += sq(e * hh * frcp(sc));
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float e = E[6] * Kn[d];
+#pragma unroll
+        for (int j = 5; j >= 0; --j) e = fmaf(E[j], K[j][d], e);
+        const float sc = fmaf(fmaxf(fabsf(y[comp(d)]), fabsf(ynew[comp(d)])), kRtol, kAtol);
+        en += sq(e * h * frcp(sc));
+    }
+    // en = error_norm^2 (omega_x and the mass contribute 0 to the sum, 1 each to the count); norm < 1 <=> en < 1, and
+    // norm^-1/5 = en^-1/10 = exp2(-0.1 log2 en)  (en == 0: exp2(+inf) = inf, cut to kMaxFactor like scipy's special case)
+    en *= (1.0f / 14.0f);
+    const float pw = kSafety * fexp2(-0.1f * flog2(en));
+    if (!(en < 1.0f)) {
+        L.h_abs *= fmaxf(kMinFactor, pw);
+        L.tries += 1;
+        return;
+    }
+    {
+        float factor = fminf(kMaxFactor, pw);
+        if (L.tries > 0) factor = fminf(1.0f, factor);
+        L.h_abs *= factor;
+        L.tries = 0;
+        L.steps += 1;
+    }
+    // ---- terminal event on the accepted sub-step (ivp.py find_active_events / handle_events) ---------
+    if (crossing(y[0], ynew[0])) {
+        // y(s) = y_old + h s (Q0 + Q1 s + Q2 s^2 + Q3 s^3), Q = K^T P; position rows through PS / PA (see Derived)
+        auto q_pos = [&](int i, float (&qq)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc = fmaf(T.PA[m][k], K[m][i], acc);
+                qq[k] = fmaf(h, acc, T.PS[k] * y[3 + i]);
+            }
+        };
+        float q[4];
+        q_pos(0, q);
+        const float cx[5] = {y[0], h * q[0], h * q[1], h * q[2], h * q[3]};
+        const float th = poly_root01(cx, y[0], ynew[0]);
+        float yev[kDyn];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float qq[4];
+            q_pos(i, qq);
+            yev[i] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[i]);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float qq[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qq[k] = fmaf(K[j][d], P[j][k], qq[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qq[k] = fmaf(Kn[d], P[6][k], qq[k]);
+            yev[comp(d)] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[comp(d)]);
+        }
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) {
+            if (i != 10) y[i] = yev[i];
+        }
+        L.t = t + th * h;
+        L.status = 1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDyn; ++i) y[i] = ynew[i];
+#pragma unroll
+        for (int d = 0; d < D; ++d) L.K0[d] = Kn[d];   // FSAL
+        L.t = t + h;
+    }
+}
+
+// End of the env step: the mass at the time reached, the quaternion renormalised (sim:97).
+__device__ __forceinline__ void rk45_end(float (&y)[kDyn], float& mass, const Control& c, const Rk45Lane& L) {
+    mass = fmaf(-c.mdot, L.t, mass);
     const float n2 = fmaf(y[6], y[6], fmaf(y[7], y[7], fmaf(y[8], y[8], y[9] * y[9])));
     const float inv = frsq(n2);
     y[6] *= inv;
     y[7] *= inv;
     y[8] *= inv;
     y[9] *= inv;
-    return status;
+}
+
+// One env step [0, dt] of the adaptive integrator.  Returns status (0 reached dt, 1 ground event,
+// -1 step size underflow -- the reference folds any non-zero status into done, env:213).
+// nfev receives the number of RHS evaluations (scipy's sol.nfev).
+__device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, const Control& c, const Inertia& J, float dt,
+                                              int& nfev) {
+    Rk45Lane L;
+    rk45_begin(y, mass, c, J, dt, L);
+#pragma unroll 1
+    while (rk45_active(L, dt)) rk45_attempt(y, mass, c, J, dt, L);
+    rk45_end(y, mass, c, L);
+    nfev = L.nfev;
+    return L.status;
 }
 
 // ---- reward (env:317-402) ------------------------------------------------------------------------

@@ -242,6 +242,12 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #ifndef R6_RK45_WAVES
 #define R6_RK45_WAVES 4    // waves per SIMD the adaptive instances are compiled for (128 registers; round 3: 1 -> 254 registers, two waves)
 #endif
+#ifndef R6_RK45_STASH
+#define R6_RK45_STASH 96   // straggler stash of the adaptive instances (entries per workgroup; see step_kernel)
+#endif
+#ifndef R6_RK45_DEFER_DEFAULT
+#define R6_RK45_DEFER_DEFAULT 6   // a wave hands its last <= 6 unfinished lanes to the workgroup's straggler pass (0 = never: every wave follows its slowest lane)
+#endif
 #ifndef R6_EULER_WAVES
 #define R6_EULER_WAVES 5   // 90 VGPRs with the register prefetch of the next tile; a budget of 4 waves lets the allocator
                            // drift past 96 and silently lose the fifth wave (34.2 -> 34.9 us when that happened)
@@ -263,11 +269,25 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     __shared__ int rq_count;
     __shared__ int wg_next;
     __shared__ stat_t blk_stats[R6_NUM_STATS];
+    // Adaptive instances: the straggler stash.  scipy's RK45 needs one step for 39 % of the env steps, two for 60 %, three or four
+    // for 0.8 % (golden G3) -- and a wave follows its slowest lane: 2.46 attempts per 64-env tile against 1.63 per lane (round 4),
+    // with 0.5 lanes per wave alive in the attempts beyond the second, and launch times that follow the unluckiest wave.  A wave
+    // therefore stops after its second attempt when at most `defer_max` lanes are still integrating: their state goes to this
+    // per-workgroup stash (structure of arrays, one column per env) and the wave finishes its tile without them.  The LAST wave
+    // of the workgroup to leave the tile loop integrates the stash densely -- one pass for the whole workgroup -- and
+    // writes those envs' outputs itself.  Same arithmetic per lane, whoever runs it: bit for bit the results without the stash
+    // (tests/test_gpu_parity.py::test_rk45_straggler_pass_is_bit_identical).
+    constexpr bool kAdaptive = (INTEG == R6_RK45);
+    constexpr int kStashCap = kAdaptive ? R6_RK45_STASH : 1;
+    constexpr int kStashWords = 34;   // env | y[13] | mass(t=0) | t, h_abs | K0[9] | nfev, tries, steps | thrust vector, thrust, mdot
+    __shared__ float stash[kAdaptive ? kStashWords : 1][kStashCap];
+    __shared__ int stash_count, waves_done;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar tile arithmetic
     float* tile = tiles[wave];
+    const int defer_max = kAdaptive ? (int)((sweep >> 8) & 0xffu) : 0;
     const int64_t n = b.n;
     const int64_t n_tiles = (n + 63) >> 6;
     // XCD-aware tile split.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 = XCC_ID, checked with
@@ -311,6 +331,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     if (tid == 0) {
         rq_count = 0;
         wg_next = kWaves;   // list entries 0..kWaves-1 are the waves' fixed first tiles
+        stash_count = 0;
+        waves_done = 0;
     }
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
     if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
@@ -328,7 +350,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         constexpr bool FULL = decltype(full_c)::value;
         bool overflow = false;       // this lane's finished episode did not fit into the reset queue
         const int64_t rem = n - e0;  // envs from the tile's start to the end of the shard (> 0)
-        const bool live = FULL ? true : (lane < rem);
+        const bool lane_live = FULL ? true : (lane < rem);
+        bool deferred = false;       // adaptive instances: this lane's env went to the straggler stash, the pass after the loop finishes it
         float y[kDyn];
 #pragma unroll
         for (int j = 0; j < kDyn; ++j) y[j] = in.y[j];
@@ -347,12 +370,67 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         int nfev = 0;
         int status;
         if constexpr (INTEG == R6_RK45) {
-            status = integrate_rk45(y, mass, c, J, p.dt, nfev);
+            // integrate_rk45() with the wave-level loop written out: attempt after attempt while any lane integrates; from the
+            // third attempt on, a remainder of at most defer_max lanes is handed to the stash instead
+            Rk45Lane L;
+            rk45_begin(y, mass, c, J, p.dt, L);
+            int attempts = 0;
+            bool may_defer = defer_max > 0;
+#pragma unroll 1
+            for (;;) {
+                const bool active = rk45_active(L, p.dt) && !deferred;
+                const uint64_t m = __ballot(active);
+                if (m == 0ull) break;
+                // (padding lanes of the shard's last tile integrate a benign state like everybody else, but nobody needs their
+                //  result: they are dropped at the hand-over and never take a stash slot -- a slot without a writer would hand the
+                //  pass an env index that was never written)
+                const uint64_t ml = FULL ? m : __ballot(active && lane_live);
+                const int cnt = __popcll(ml);
+                if (may_defer && attempts >= 2 && cnt <= defer_max) {
+                    if (cnt > 0) {
+                        const int first = __builtin_ctzll(ml);
+                        int base = 0;
+                        if (lane == first) base = atomicAdd(&stash_count, cnt);
+                        base = __builtin_amdgcn_readlane(base, first);
+                        if (active && lane_live) {
+                            const int slot = base + __popcll(ml & ((1ull << lane) - 1ull));
+                            if (slot < kStashCap) {
+                                stash[0][slot] = __int_as_float((int)(e0 + lane));
+#pragma unroll
+                                for (int j = 0; j < kDyn; ++j) stash[1 + j][slot] = y[j];
+                                stash[14][slot] = mass;
+                                stash[15][slot] = L.t;
+                                stash[16][slot] = L.h_abs;
+#pragma unroll
+                                for (int d = 0; d < dp45::D; ++d) stash[17 + d][slot] = L.K0[d];
+                                stash[26][slot] = __int_as_float(L.nfev);
+                                stash[27][slot] = __int_as_float(L.tries);
+                                stash[28][slot] = __int_as_float(L.steps);
+                                stash[29][slot] = c.tbx;
+                                stash[30][slot] = c.tby;
+                                stash[31][slot] = c.tbz;
+                                stash[32][slot] = c.thrust;
+                                stash[33][slot] = c.mdot;
+                                deferred = true;
+                            }
+                        }
+                    }
+                    if (active && !lane_live) deferred = true;
+                    may_defer = false;   // one hand-over per tile; lanes that found the stash full go on in this wave
+                    continue;
+                }
+                if (active) rk45_attempt(y, mass, c, J, p.dt, L);
+                ++attempts;
+            }
+            rk45_end(y, mass, c, L);
+            status = L.status;
+            nfev = L.nfev;
         } else {
             status = integrate<INTEG, true, ONE>(y, mass, c, J, p.dt, p.n_substeps);
             nfev = (INTEG == R6_RK4 ? 4 : 1) * (ONE ? 1 : p.n_substeps);
         }
 #endif
+        const bool live = lane_live && !deferred;   // a deferred lane's rows of this tile are written by the straggler pass
 
         // `ln` = the lane id again, opaque to the optimiser: everything addressed after the integration is
         // re-derived from it here instead of being hoisted out of the tile loop and kept in VGPRs across
@@ -678,6 +756,127 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     }
     }   // !kEarly
     __builtin_amdgcn_s_setprio(0);
+
+    // ---- adaptive instances: the straggler pass (see `stash` above).  The last wave of the workgroup to get here integrates every
+    //      env the workgroup's waves have handed over, 64 at a time, and does for them what process_tile does for a tile's lanes --
+    //      with per-lane addresses, since these envs come from all over the workgroup's tiles. ----------------------------------
+    if constexpr (kAdaptive) {
+        if (defer_max > 0) {
+            // this wave's tile stores are acknowledged before it reports in: the pass overwrites rows (the observation block of a
+            // tile is stored whole, a deferred lane's row included) and must come second
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            int arrived = 0;
+            if (lane == 0) arrived = atomicAdd(&waves_done, 1);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == kWaves - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int n_in = __builtin_amdgcn_readfirstlane(__atomic_load_n(&stash_count, __ATOMIC_RELAXED));
+                const int n_s = n_in < kStashCap ? n_in : kStashCap;
+#pragma unroll 1
+                for (int base = 0; base < n_s; base += 64) {
+                    const bool valid = base + lane < n_s;
+                    const int e = valid ? base + lane : 0;
+                    const R6Buffers bb = load_buffers();
+                    const int64_t ld = bb.ld;
+                    const int64_t i = (int64_t)__float_as_int(stash[0][e]);
+                    float y[kDyn];
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) y[j] = stash[1 + j][e];
+                    float mass = stash[14][e];
+                    Rk45Lane L;
+                    L.t = valid ? stash[15][e] : p.dt;    // an idle lane of the pass: nothing to integrate
+                    L.h_abs = stash[16][e];
+#pragma unroll
+                    for (int d = 0; d < dp45::D; ++d) L.K0[d] = stash[17 + d][e];
+                    L.nfev = __float_as_int(stash[26][e]);
+                    L.tries = __float_as_int(stash[27][e]);
+                    L.steps = __float_as_int(stash[28][e]);
+                    L.status = 0;
+                    Control c;
+                    c.tbx = stash[29][e];
+                    c.tby = stash[30][e];
+                    c.tbz = stash[31][e];
+                    c.thrust = stash[32][e];
+                    c.mdot = stash[33][e];
+                    const float m0 = bb.epconst[i];
+                    float v0 = 0.0f;
+                    if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = bb.epconst[ld + i];
+                    uint32_t ep_step = 0u;
+                    float ep_ret = 0.0f;
+                    if (has_ep) {
+                        ep_step = bb.ep_step[i];
+                        ep_ret = bb.ep_return[i];
+                    }
+                    const Inertia J = make_inertia(m0);
+#pragma unroll 1
+                    while (__any(rk45_active(L, p.dt))) {
+                        if (rk45_active(L, p.dt)) rk45_attempt(y, mass, c, J, p.dt, L);
+                    }
+                    rk45_end(y, mass, c, L);
+                    const int status = L.status, nfev = L.nfev;
+                    // termination, reward, fused wrappers, outputs: process_tile's sequence, operation for operation
+                    const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
+                    bool done = (status != 0) || bnd, truncated = false;
+                    RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
+                    const bool landed = rw.landed;
+                    float rew = finalize_reward(p, rw, bnd, fmaf(2.0f * c.thrust, frcp(p.max_thrust), -1.0f), y);
+                    if (valid && bb.terms) {
+#pragma unroll
+                        for (int q = 0; q < R6_NUM_TERMS; ++q) bb.terms[q * ld + i] = rw.terms[q];
+                    }
+                    if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
+                    ep_step += 1u;
+                    ep_ret += rew;
+                    if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
+                        truncated = !done;
+                        done = true;
+                    }
+                    bool overflow = false;
+                    if (valid) {
+                        bb.reward[i] = rew;
+                        bb.done[i] = done ? 1 : 0;
+#pragma unroll
+                        for (int j = 0; j < kDyn; ++j) bb.state[j * ld + i] = y[j];
+                        bb.state[kDyn * ld + i] = mass;
+                        if (has_ep) {
+                            bb.ep_step[i] = ep_step;
+                            bb.ep_return[i] = ep_ret;
+                        }
+                        if (bb.flags)
+                            bb.flags[i] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
+                        if (bb.nfev) bb.nfev[i] = (uint8_t)(nfev > 255 ? 255 : nfev);
+                        float ob[OD];
+#pragma unroll
+                        for (int j = 0; j < kDyn; ++j) {
+                            if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
+                        }
+                        if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
+#pragma unroll
+                        for (int j = 0; j < OD; ++j) bb.obs[i * OD + j] = ob[j];
+                        if (done) {
+                            if (bb.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
+                            if (p.auto_reset) {
+                                if (bb.final_obs) {
+#pragma unroll
+                                    for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = ob[j];
+                                }
+                                if (bb.fin_return) bb.fin_return[i] = ep_ret;
+                                if (bb.fin_length) bb.fin_length[i] = ep_step;
+                                const int slot = atomicAdd(&rq_count, 1);
+                                if (slot < kResetQueueCap) rq[slot] = (int)i;
+                                else overflow = true;
+                            }
+                        }
+                    }
+                    if (__builtin_expect(__any(overflow), 0)) {
+                        __builtin_amdgcn_s_waitcnt(0);
+                        if (overflow) reset_env_global<OD>(load_params(), bb, i, seed, step_index, env_offset);
+                    }
+                }
+            }
+        }
+    }
 
 #ifdef R6_PHASE_TIMING
     const uint64_t pt1 = wall_clock64();
@@ -1713,11 +1912,13 @@ struct StepTune {
     std::atomic<int> sweep_flags{0};                         // A/B bit passed to the kernel: 4 = no priority ladder
     std::atomic<int> balanced_tpw{0};                        // tiles per wave of the dispatcher-balanced grid (large shards); 0 = by shard size
     std::atomic<int> nt_mode{-1};                            // -1: streaming stores by shard size (default), 0: never, 1: always
+    std::atomic<int> rk45_defer{R6_RK45_DEFER_DEFAULT};      // adaptive instances: a wave hands at most this many unfinished lanes to the straggler pass (0 = never)
     StepTune() {
         if (const char* e = std::getenv("R6_EVEN_XCD_SHARE")) even_share = std::atof(e);
         if (const char* e = std::getenv("R6_GRID_BLOCKS")) grid_blocks = std::atoi(e);
         if (const char* e = std::getenv("R6_SWEEP")) sweep = std::atoi(e);
         if (const char* e = std::getenv("R6_BALANCED_TPW")) balanced_tpw = std::atoi(e);
+        if (const char* e = std::getenv("R6_RK45_DEFER")) rk45_defer = std::atoi(e);
     }
 };
 StepTune& tune() {
@@ -1788,6 +1989,11 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
     uint32_t sweep = 0;
     if (step & 1) sweep = (blocks > cap || sweep_mode == 2) ? 2u : (sweep_mode == 1 ? 1u : 0u);
     sweep |= (uint32_t)tune().sweep_flags.load(std::memory_order_relaxed) & 4u;
+    if constexpr (INTEG == R6_RK45) {   // bits 8..15: the straggler hand-over threshold (see step_kernel)
+        int dm = tune().rk45_defer.load(std::memory_order_relaxed);
+        dm = dm < 0 ? 0 : (dm > 64 ? 64 : dm);
+        sweep |= (uint32_t)dm << 8;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(r6::kBlock), 0, s, p, b, seed, step, off, even_share, sweep);
 }
 
@@ -1949,6 +2155,7 @@ int r6_tune(const char* key, double value) {
     else if (!std::strcmp(key, "sweep_flags")) t.sweep_flags = (int)value;
     else if (!std::strcmp(key, "balanced_tiles_per_wave")) t.balanced_tpw = (int)value;
     else if (!std::strcmp(key, "streaming_stores")) t.nt_mode = (int)value;
+    else if (!std::strcmp(key, "rk45_defer")) t.rk45_defer = (int)value;
     else return fail(R6_E_BADARG, "r6_tune: unknown key");
     return 0;
 }

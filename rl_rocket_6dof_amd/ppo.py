@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Sequence
 
@@ -373,6 +374,10 @@ class PPO:
         self.cfg = cfg = config or PPOConfig()
         self.device = env.device
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the gradient all-reduce is issued whenever several ranks exist -- or one rank with R6_FORCE_PROCESS_GROUP=1 (a builder's
+        # rehearsal of the multi-rank code path, collectives included, on the one GPU a box has)
+        self._collectives = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("R6_FORCE_PROCESS_GROUP") == "1")
+        self.graph_collective_error = None   # what RCCL / torch said if the all-reduce refused to be captured into the epoch graph
         torch.manual_seed(cfg.seed)          # identical initial weights on every rank
         self.policy = (policy or ActorCritic(env.obs_dim, 3, cfg.net_arch, cfg.log_std_init, cfg.shared_trunk)).to(self.device)
         capt = self.device.type == "cuda" and cfg.graph_update
@@ -610,7 +615,7 @@ class PPO:
         self._gae(self.policy.value(self._obs).contiguous())
 
     def _sync_grads(self):
-        if self.world == 1:
+        if not self._collectives:
             return
         grads = [p.grad for p in self.policy.parameters() if p.grad is not None]
         # one bucket (~10^4 parameters); each rank's gradient (a mean over ITS minibatch) enters with its share of the
@@ -636,7 +641,7 @@ class PPO:
             if norm is None and cfg.normalize_advantage and mb.numel() > 1:
                 norm = self.fused_update.adv_norm(adv, mb)
             self.fused_update(obs, act, old_logp, adv, ret, mb, norm, cfg.clip_range, cfg.vf_coef, cfg.ent_coef)
-            if self.world > 1:     # one bucket, already flat: each rank's mean gradient enters with its share of the samples
+            if self._collectives:     # one bucket, already flat: each rank's mean gradient enters with its share of the samples
                 g = self.fused_update.flat_g
                 g.mul_(self._grad_weight)
                 if dist.get_backend() == "nccl":
@@ -700,8 +705,14 @@ class PPO:
         replayed: at minibatches of <= 2^17 samples the ~250 kernels of a torch step are launch-bound in eager mode
         (2.1 ms per step at 65 536 samples against ~0.4 ms of GPU work), and with the fused kernels (4 launches,
         ~0.09 ms per step) even one index copy + one graph launch per STEP is a fifth of the time -- so a whole
-        epoch's steps (up to 32) share one replay and one copy of the permutation.  Single-process only (no
-        collective inside)."""
+        epoch's steps (up to 32) share one replay and one copy of the permutation.
+
+        Several ranks (round 5; round 4 kept multi-rank updates eager, 160 launch-bound steps per iteration in exactly the
+        configuration BASELINE configs[4] names): the gradient all-reduce of every step is captured INTO the graph -- RCCL's
+        collectives are stream-ordered kernel launches like any other; torch's process group forks to its own stream and joins
+        back inside the capture.  Every rank captures the same sequence (the step count per epoch is agreed in __init__), the
+        communicator exists by then (the first three steps of a job always run eagerly).  If the stack refuses the capture, the
+        error text is kept in ``graph_collective_error``, None is returned and the update stays eager for the rest of the job."""
         key = (bs, chunk, total) + tuple(t.data_ptr() for t in flat)
         if self._graph is not None and self._graph_key == key:
             return self._graph
@@ -713,15 +724,25 @@ class PPO:
             self.fused_update.adv_norm(flat[3], self._mb_idx[:chunk * bs], chunk)     # allocates its buffers outside the capture
         self._graph = torch.cuda.CUDAGraph()
         idx = self._mb_idx[:chunk * bs]
-        with torch.cuda.graph(self._graph):
-            if total:
-                self._permute(self._mb_idx[:total], self._perm_base)
-                self._perm_base.add_(1)
-            norms = None
-            if batched_norm:
-                norms = self.fused_update.adv_norm(flat[3], idx, chunk).view(chunk, 2)   # the whole chunk's minibatches at once
-            for c in range(chunk):
-                self._minibatch_step(self._mb_idx[c * bs:(c + 1) * bs], flat, self._acc, None if norms is None else norms[c])
+        perm_count0 = self._perm_count
+        try:
+            # thread_local: the process group's watchdog thread may query its events while this thread captures
+            with torch.cuda.graph(self._graph, **({"capture_error_mode": "thread_local"} if self._collectives else {})):
+                if total:
+                    self._permute(self._mb_idx[:total], self._perm_base)
+                    self._perm_base.add_(1)
+                norms = None
+                if batched_norm:
+                    norms = self.fused_update.adv_norm(flat[3], idx, chunk).view(chunk, 2)   # the whole chunk's minibatches at once
+                for c in range(chunk):
+                    self._minibatch_step(self._mb_idx[c * bs:(c + 1) * bs], flat, self._acc, None if norms is None else norms[c])
+        except Exception as e:   # noqa: BLE001
+            if not self._collectives:
+                raise
+            self.graph_collective_error = f"{type(e).__name__}: {e}"[:600]
+            self._graph, self._graph_key, self._perm_count = None, None, perm_count0
+            torch.cuda.synchronize(self.device)
+            return None
         self._graph_key = key
         return self._graph
 
@@ -740,7 +761,9 @@ class PPO:
                 self.adv.reshape(total), self.ret.reshape(total))
         bs = self._bs
         keys = ("pg_loss", "v_loss", "entropy", "clip_frac", "approx_kl")
-        use_graph = cfg.graph_update and self.device.type == "cuda" and self.world == 1 and bs <= (1 << 17)
+        # several ranks: only over RCCL (a gloo all-reduce is host code), and only while the capture has not been refused
+        coll_ok = not self._collectives or (dist.get_backend() == "nccl" and self.graph_collective_error is None)
+        use_graph = cfg.graph_update and self.device.type == "cuda" and coll_ok and bs <= (1 << 17)
         acc = torch.zeros(len(keys), dtype=torch.float32, device=self.device)   # summed on the device: no per-batch sync
         if self.fused_update is not None:
             self.fused_update.stats[8:].zero_()      # the gradient kernel keeps the running sums itself
@@ -752,9 +775,12 @@ class PPO:
             self._perm_buf = torch.zeros(total, dtype=torch.int64, device=self.device)
         for _ in range(cfg.n_epochs):
             if fast and use_graph and chunk == steps and self._eager_steps >= 3:
-                self._graphed_steps(flat, bs, chunk, total).replay()      # permutation + every minibatch step of the epoch: one replay
-                n_batches += steps
-                continue
+                g = self._graphed_steps(flat, bs, chunk, total)           # permutation + every minibatch step of the epoch: one replay
+                if g is not None:
+                    g.replay()
+                    n_batches += steps
+                    continue
+                use_graph = False                                         # the capture was refused (several ranks): eager from here on
             perm = self._permute(self._perm_buf) if fast else torch.randperm(total, device=self.device, generator=self.gen)
             norms = None
             if self.fused_update is not None and cfg.normalize_advantage and bs > 1 and steps > 1:
@@ -764,8 +790,10 @@ class PPO:
             while s < steps:
                 # the first steps run eagerly (allocator / Adam state warm-up), and so does the rest of that epoch when
                 # it is shorter than a chunk
-                if use_graph and self._eager_steps >= 3 and s + chunk <= steps:
-                    g = self._graphed_steps(flat, bs, chunk)
+                g = self._graphed_steps(flat, bs, chunk) if (use_graph and self._eager_steps >= 3 and s + chunk <= steps) else None
+                if g is None and self.graph_collective_error is not None:
+                    use_graph = False
+                if g is not None:
                     self._mb_idx[:chunk * bs].copy_(perm[s * bs:(s + chunk) * bs])
                     g.replay()
                     s += chunk

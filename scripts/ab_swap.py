@@ -30,8 +30,8 @@ dev = torch.device("cuda:0")
 n = args.n
 libs = [x.split("=") for x in args.libs.split(",")]
 handles = {name: _lib.load(path) for name, path in libs}
-KEYS = {"even": "even_xcd_share", "grid": "grid_blocks", "sweep": "sweep", "flags": "sweep_flags", "tpw": "balanced_tiles_per_wave", "nt": "streaming_stores"}
-DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0, "balanced_tiles_per_wave": 0, "streaming_stores": -1}
+KEYS = {"even": "even_xcd_share", "grid": "grid_blocks", "sweep": "sweep", "flags": "sweep_flags", "tpw": "balanced_tiles_per_wave", "nt": "streaming_stores", "defer": "rk45_defer"}
+DEFAULTS = {"even_xcd_share": -1.0, "grid_blocks": 0, "sweep": -1, "sweep_flags": 0, "balanced_tiles_per_wave": 0, "streaming_stores": -1, "rk45_defer": 6}
 
 
 def apply(shape, lib):

@@ -54,3 +54,44 @@ def test_bench_single_gpu_prints_one_contract_line():
     assert 60 < line["rk45"]["us_per_env_step"] < 300 and line["rk45"]["integrator"] == "rk45"
     assert "issue_time_us_per_simd" in line["valu"] and "busy_frac" not in line["valu"]
     assert line["configs1"]["k16"]["roofline"]["bound"] == "dependent_chain_of_one_tile_per_simd"
+
+
+def test_driver_shape_20_steps_sits_in_its_own_steady_distribution():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- the driver's exact command shape (round-4 review, Next 1; side figures and
+    CPU baseline switched off here, they run after the timed region and do not touch it).  What round 5 measured about it
+    (DESIGN.md section 6): the 20 launches last 0.8 ms; the chip has slow episodes of 1.5-3 ms at +5 ... +15 % that arrive every
+    8-25 ms, do NOT replay with the data (the same deterministic sequence run twice: 41 and 34 slow 20-launch chunks, 1 in common) and
+    hit 15-25 % of all 20-launch windows.  So one 20-launch sample cannot be held to 4 % of the steady median every time -- what can
+    be asserted, and is:
+      * every run: the timed region lies inside the [min, max] of the 100 chunk means of the `steady` record taken right behind
+        it in the same process (it is a sample of that distribution, nothing else is going on), and its wall-clock figure exceeds
+        its HIP-event figure by no more than the 20-step shape's fixed costs (first launch after the barrier + host wake-up);
+      * of at most three runs, one has its 20-step kernel mean within 4 % of its own 2000-launch steady median (three misses in a
+        row have a probability below 2 % at the measured slow share)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    attempts, ok = [], False
+    for _ in range(3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras",
+                            "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        st = line["steady"]
+        assert line["steps"] == 20 and line["warmup"] == 5 and st["chunks"] == 100 and st["chunk_launches"] == 20
+        assert "1 s of untimed stepping" in line["config"]["workload"]
+        k_us, wall_us = line["roofline"]["kernel_us"], line["ms_per_step"] * 1e3
+        attempts.append({"kernel_us": k_us, "wall_us": wall_us, "steady": {k: st[k] for k in ("median", "p10", "p90", "min", "max", "mean")},
+                         "slow_share": st["share_of_chunks_above_1.06_x_median"]})
+        assert st["min"] * 0.97 <= k_us <= st["max"] * 1.03, attempts[-1]
+        assert 0.0 <= wall_us - k_us < 3.0, attempts[-1]            # measured: +0.9 ... +1.0 us per step at 20 steps
+        assert 0.55 < line["roofline"]["frac"] < 0.8
+        if abs(k_us / st["median"] - 1.0) <= 0.04:
+            ok = True
+            break
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(attempts, open(os.path.join(ROOT, "gpurun_out", "driver_shape_attempts.json"), "w"), indent=1)
+    except OSError:
+        pass
+    print(f"[driver shape] {len(attempts)} run(s): " + "; ".join(f"20-step {a['kernel_us']:.2f} us vs steady median {a['steady']['median']:.2f} "
+                                                                 f"(p10 {a['steady']['p10']:.2f}, p90 {a['steady']['p90']:.2f})" for a in attempts))
+    assert ok, attempts

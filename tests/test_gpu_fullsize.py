@@ -119,6 +119,45 @@ def test_determinism_and_sharding_invariance(torch_cuda, cfg):
     assert torch.equal(full.done[N // 2:], hi.done)
 
 
+@pytest.mark.parametrize("n,groups,sync,wrapped", [(N, 2, "caller", False), (200_003, 3, "caller", True), (N // 2 + 77, 2, "none", True)])
+def test_env_groups_on_their_own_streams_change_nothing(torch_cuda, cfg, n, groups, sync, wrapped):
+    """BatchedRocket6DOF(groups=G): step_async issues G launches, one per contiguous env group, on streams the env owns (one
+    group's ramp and tail under the other's bulk; round-4 review, Next 4).  Envs are independent and the reset RNG is keyed by the
+    global env index, so every output, the state, the episode counters and the (exact) episode statistics equal the one-launch
+    env's, bit for bit -- with the per-step fork / join against the caller's stream ("caller") and without ("none": the groups
+    as independent pipelines, joined once at the end); odd sizes, the fused wrappers and the optional outputs included."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    kw = dict(seed=5, record_flags=True, record_terms=wrapped, track_episodes=True)
+    if wrapped:
+        kw.update(remove_mass=True, clip_reward=(-1, 100), max_episode_steps=40)
+    one = BatchedRocket6DOF(n, cfg, **kw)
+    grp = BatchedRocket6DOF(n, cfg, groups=groups, group_sync=sync, **kw)
+    assert grp._group_bounds[0] == 0 and grp._group_bounds[-1] == n and all(b % 64 == 0 for b in grp._group_bounds[:-1])
+    one.reset()
+    grp.reset()
+    g = torch.Generator(device=one.device).manual_seed(3)
+    steps = 120
+    acts = [(torch.rand((n, 3), generator=g, device=one.device) * 2 - 1) for _ in range(4)]
+    torch.cuda.synchronize()      # "none": the action pool is complete before any group stream reads it
+    for k in range(steps):
+        a = acts[k % 4]
+        one.step_async(a)
+        grp.step_async(a)
+        if sync == "caller":
+            o1, r1, d1, _ = one.step_wait()
+            o2, r2, d2, _ = grp.step_wait()
+            if k % 40 == 7:       # ordered against the caller's stream: readable right here
+                assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    grp.join_groups()
+    torch.cuda.synchronize()
+    assert int(one.episode_stats(clear=False)["episodes"]) > (1000 if wrapped else 200)
+    assert one.episode_stats(clear=False) == grp.episode_stats(clear=False)
+    for name in ("state", "epconst", "obs", "reward", "done", "flags", "final_obs", "ep_step", "ep_return", "fin_return", "fin_length") + (("terms",) if wrapped else ()):
+        assert torch.equal(getattr(one, name), getattr(grp, name)), name
+
+
 @pytest.mark.parametrize("n", [3 << 21, 1 << 21])
 def test_streaming_store_form_matches_the_plain_form(torch_cuda, cfg, n):
     """From 3 * 2^21 envs on, and (round 4) between 1.2 M and 2.36 M envs, the launcher picks the kernel form whose obs / reward /

@@ -283,9 +283,19 @@ def test_g6_free_running_rollouts(torch_cuda, cfg, P, name, integ, h):
                 e = assert_close_scaled(st[r], ys[r][k + 1], P.normalizer, 4.0 * floors[r], f"{name} rollout {r} step {k}")
                 curve[r].append(e)
                 worst[r] = max(worst[r], e)
+    # Teeth (round-4 review, Weak 1): 4 x floor alone would let a regression that doubles the drift pass on the flights that
+    # matter (rk4_0.04 #0: measured 5.2e-5 against 4 x 9.6e-5).  The whole-flight bound is therefore
+    #     min(4 x floor, max(2 x the drift measured on MI355X in round 4, 1 x floor))
+    # -- twice the recorded value (tests/golden/g6_measured_drift.json), except where that value lies below the flight's own
+    # float32 floor (a drift below the floor is luck of the rounding, not a property to hold a kernel to).
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_measured_drift.json")))[name]
     for r in range(2):
+        measured = rec["worst_scaled_drift_measured_on_mi355x"][r]
+        bound = min(4.0 * floors[r], max(2.0 * measured, floors[r]))
         print(f"[G6 rollout {name} #{r}] worst scaled drift over {len(acts[r])} steps {worst[r]:.2e} = {worst[r] / floors[r]:.2f} x the "
-              f"float32 floor of this flight ({floors[r]:.2e}); asserted <= 4 x")
+              f"float32 floor of this flight ({floors[r]:.2e}); recorded in round 4: {measured:.2e}; asserted <= {bound:.2e} "
+              f"(per step <= 4 x floor)")
+        assert worst[r] <= bound, (name, r, worst[r], bound)
     try:      # the drift as a function of the step count (gpurun_out/g6_drift_curves.json)
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "g6_drift_curves.json")
         data = json.load(open(path)) if os.path.exists(path) else {}
@@ -610,6 +620,60 @@ def test_rk45_adaptive_twin_vs_reference(torch_cuda, cfg, P, fixture):
     print(f"[{fixture} rk45] nfev identical to scipy on {100 * same:.1f}% of the steps "
           f"(mean {nfev.mean():.2f} vs {G['nfev'].mean():.2f})")
     assert same > 0.97 and abs(nfev.mean() - G["nfev"].mean()) < 0.2
+
+
+@pytest.mark.parametrize("n,kw", [(150_037, dict()),
+                                  (9_001, dict(remove_mass=True, clip_reward=(-1, 100), max_episode_steps=7, reward_shaping="velocity"))])
+def test_rk45_straggler_pass_is_bit_identical(torch_cuda, cfg, n, kw):
+    """integrator="rk45": a wave hands its last few unfinished lanes (the 0.8 % of env steps that need a third or fourth RK step,
+    simulator.py:83-88 through scipy's step control) to the workgroup's straggler pass instead of following them
+    (r6_kernels.hip step_kernel, r6_tune("rk45_defer")).  Whoever integrates a lane does the same arithmetic: every output of every
+    step -- observation, reward, done, flag byte, nfev, the 7 reward terms, terminal observation / return / length, the state, the
+    episode counters and statistics -- must equal the run without the hand-over, bit for bit; ragged last tile, in-kernel resets,
+    the fused wrappers and velocity shaping included.  Also: the pass really ran (steps with nfev >= 20 exist), and a threshold of
+    64 lanes with a full stash (everybody defers, the stash overflows, the rest goes on in the wave) changes nothing either."""
+    torch = torch_cuda
+    import json
+
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, _lib
+
+    c2 = json.loads(json.dumps(cfg))
+    if kw.pop("reward_shaping", None) == "velocity":
+        c2["reward_shaping_type"] = "velocity"
+        c2["landing_params"]["waypoint"] = 50
+    K = 24
+    gen = torch.Generator(device="cuda:0").manual_seed(7)
+    acts = [(torch.rand((n, 3), generator=gen, device="cuda:0") * 2 - 1) for _ in range(K)]
+    G4 = load_golden("g4_ground_events.npz")
+    runs = []
+    try:
+        for defer in (0, 6, 64):
+            _lib.tune("rk45_defer", defer)
+            env = BatchedRocket6DOF(n, c2, integrator="rk45", seed=3, record_flags=True, record_terms=True, record_nfev=True,
+                                    track_episodes=True, **kw)
+            env.reset()
+            st = env.get_state().cpu().numpy()
+            k4 = min(n // 3, len(G4["pre"]))            # a third of the batch a few metres above the pad: ground events, goal rewards, resets
+            st[:k4] = G4["pre"][:k4].astype(np.float32)
+            env.set_state(st)
+            snaps = []
+            for k in range(K):
+                env.step_async(acts[k])
+                snaps.append([t.clone() for t in (env.obs, env.reward, env.done, env.flags, env.nfev, env.terms, env.final_obs, env.fin_return,
+                                                  env.fin_length, env.state, env.ep_step, env.ep_return)])
+            torch.cuda.synchronize()
+            snaps.append([env.stats.sum(0).clone()])
+            runs.append(snaps)
+            del env
+    finally:
+        _lib.tune("rk45_defer", 6)
+    nf = torch.stack([s[4] for s in runs[0][:K]])
+    assert int((nf >= 20).sum()) > K, "no env step needed a third RK step: the straggler pass was not exercised"
+    assert int(torch.stack([s[2] for s in runs[0][:K]]).sum()) > 200      # episode ends (ground events of the G4 states, bounds, time limit): resets ran
+    for other in runs[1:]:
+        for k, (a, b) in enumerate(zip(runs[0], other)):
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), (k, i)
 
 
 def test_rk45_simulator_smoke_case_single_step(torch_cuda):
