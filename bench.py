@@ -574,6 +574,55 @@ def ppo_side_measurement(torch, dev, iters: int = 5, warm: int = 3) -> dict:
     return out
 
 
+def ppo_configs4_side_measurement(torch, dev, iters: int = 2, warm: int = 2) -> dict:
+    """The ONE-GPU share of BASELINE configs[4] ("1 048 576 envs x 8 GPUs + SB3 PPO MLP(64,64), RCCL all-gather of returns"): 2^20
+    wrapped envs (the reference's make_env() stack, main_6DOF.py:44-53), SB3's default topology -- two separate tanh MLPs (64, 64)
+    (test_6DOF_sb_integration.py:31) -- 64 steps per rollout, 10 epochs of 1024 minibatches of 65 536 samples, and the design's one
+    collective per rollout, the gather of the episode summary (a local copy with one rank; RCCL with several).  What an 8-GPU job
+    adds per rank: the gradient all-reduce inside every minibatch step, captured into the same graph
+    (tests/test_gpu_ppo.py::test_multi_rank_update_runs_from_a_graph_with_the_all_reduce_inside).  A side figure of the line."""
+    from rl_rocket_6dof_amd import BatchedRocket6DOF, default_env_config
+    from rl_rocket_6dof_amd import dist as r6dist
+    from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
+
+    n, steps, bs = 1 << 20, 64, 1 << 16
+    out = {"workload": "PPO, one GPU's share of BASELINE configs[4]: 2^20 wrapped envs (remove-mass obs, reward clip, 1500-step limit) x 64 steps per "
+                       "rollout, two separate tanh MLPs (64, 64), 10 epochs x 1024 minibatches of 65 536 samples, one episode-summary gather per "
+                       "rollout, random initial weights"}
+    try:
+        env = BatchedRocket6DOF(n, default_env_config(), remove_mass=True, clip_reward=(-1, 100), max_episode_steps=1500, seed=1, device=dev)
+        algo = PPO(env, PPOConfig(n_steps=steps, batch_size=bs, net_arch=(64, 64), shared_trunk=False, log_std_min=-2.5))
+        gathered = []
+        for _ in range(warm):
+            algo.collect_rollouts()
+            gathered.append(r6dist.gather_episode_stats_device(env.episode_stats_tensor()))
+            algo.train()
+        torch.cuda.synchronize()
+        roll = upd = 0.0
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            algo.collect_rollouts()
+            gathered.append(r6dist.gather_episode_stats_device(env.episode_stats_tensor()))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            algo.train()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            roll += t1 - t0
+            upd += t2 - t1
+        roll, upd = roll / iters, upd / iters
+        mb = 10 * (steps * n // bs)
+        out.update({"env_steps_per_s": steps * n / (roll + upd), "rollout_gae_and_gather_ms": roll * 1e3, "update_ms": upd * 1e3,
+                    "minibatch_steps_per_iteration": mb, "minibatch_step_us": upd / mb * 1e6, "iterations_timed": iters,
+                    "rollout_us_per_env_step_of_the_batch": roll / steps * 1e6, "fused_update": algo.fused_update is not None,
+                    "update_from_graph": algo._graph is not None, "episodes_in_last_gather": float(gathered[-1][:, 0].sum())})
+        del algo, env, gathered
+        torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001 -- a side figure must not cost the line
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) -> dict:
     """The N > 1 record's second loop, itemised (rank-reduced with max over ranks):
       first_gather_us   the very first all-gather of the process (communicator creation, buffer registration) timed alone,
@@ -881,6 +930,7 @@ def main(argv=None):
                       "bound by arithmetic (8-20 RHS evaluations per env step, the wave follows its slowest lane), not by HBM")
             extras["two_groups"] = two_groups_side_measurement(torch, dev, cfg)
             extras["ppo_training"] = ppo_side_measurement(torch, dev)
+            extras["ppo_configs4"] = ppo_configs4_side_measurement(torch, dev)
         if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:
             extras["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         line = build_line(args, world, n, dt, wall, kernel_ms, traffic=traffic, traffic_source=source, extras=extras)

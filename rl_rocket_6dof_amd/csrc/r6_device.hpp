@@ -550,12 +550,18 @@ __device__ __forceinline__ constexpr int comp(int d) { return d < 7 ? 3 + d : 4 
 struct Rk45Lane {
     float K0[dp45::D];   // f(y) of the step in progress (FSAL: f(y_new) of the step before)
     float t, h_abs;      // time reached within [0, dt]; step size the next attempt starts from
-    int nfev;            // RHS evaluations so far (scipy's sol.nfev)
-    int status;          // 0 integrating, 1 ground event, -1 step size underflow
-    int tries;           // rejected attempts of the step in progress (scipy's step_rejected <=> tries > 0)
-    int steps;           // accepted steps
+    // One word for the bookkeeping (the attempt loop runs at the register limit of four waves per SIMD: three counters more were
+    // ten scratch loads per attempt): bits 0..1 status + 1 (1 integrating, 2 ground event, 0 step size underflow),
+    // bits 2..8 rejected attempts of the step in progress (scipy's step_rejected <=> tries > 0), bits 9..31 attempts made so far.
+    uint32_t ctl;
 };
-__device__ __forceinline__ bool rk45_active(const Rk45Lane& L, float dt) { return L.status == 0 && L.t < dt && L.steps < 4096; }
+__device__ __forceinline__ int rk45_status(const Rk45Lane& L) { return (int)(L.ctl & 3u) - 1; }
+__device__ __forceinline__ int rk45_tries(const Rk45Lane& L) { return (int)((L.ctl >> 2) & 127u); }
+__device__ __forceinline__ int rk45_attempts(const Rk45Lane& L) { return (int)(L.ctl >> 9); }
+__device__ __forceinline__ int rk45_nfev(const Rk45Lane& L) { return 2 + 6 * rk45_attempts(L); }   // scipy's sol.nfev: 2 for the initial step, 6 per attempt
+// integrating, not at the end of the env step, and fewer than 4096 attempts behind it (scipy has no such bound; a lane that hits it
+// leaves with status 0 short of dt, like round 4's guard of 4096 accepted steps -- neither is reached by a finite state)
+__device__ __forceinline__ bool rk45_active(const Rk45Lane& L, float dt) { return (L.ctl & 3u) == 1u && L.t < dt && (L.ctl >> 9) < 4096u; }
 
 // the force / torque / kinematics part of the RHS at state `ya` (only ya[0], ya[3..12] are read), into a stage vector
 __device__ __forceinline__ void rk45_eval(const float (&ya)[kDyn], float im, const Control& c, const Inertia& J, float (&k)[dp45::D]) {
@@ -612,10 +618,7 @@ __device__ __forceinline__ void rk45_begin(const float (&y)[kDyn], float mass, c
         L.h_abs = fminf(fminf(100.0f * h0, h1), dt);
     }
     L.t = 0.0f;
-    L.nfev = 2;
-    L.status = 0;
-    L.tries = 0;
-    L.steps = 0;
+    L.ctl = 1u;
 }
 
 // ONE attempt of a step (rk.py _step_impl: rk_step, error norm, accept / reject, next step size) and, when it was accepted, the
@@ -629,10 +632,15 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
     float K[6][D];    // stages 1..6 of the attempt; K[0] = L.K0
     float Kn[D];      // f(y_new)
     float ynew[kDyn];
-    const float min_step = 1e-6f * dt;   // fp32 stand-in for scipy's 10 ulp(t)
-    if (L.tries == 0) L.h_abs = fmaxf(L.h_abs, min_step);   // a new step starts
-    if (L.h_abs < min_step || L.tries >= 64) {
-        L.status = -1;
+    // (dt is wave-uniform; re-derived from the scalar here on purpose: hoisted out of the caller's attempt loop the product lives in
+    //  a vector register that loop does not have -- it came back as a scratch load, waited for on the spot, in every attempt)
+    float dts = dt;
+    asm volatile("" : "+s"(dts));
+    const float min_step = 1e-6f * dts;   // fp32 stand-in for scipy's 10 ulp(t)
+    const int tries = rk45_tries(L);
+    if (tries == 0) L.h_abs = fmaxf(L.h_abs, min_step);   // a new step starts
+    if (L.h_abs < min_step || tries >= 64) {
+        L.ctl &= ~3u;   // status -1
         return;
     }
     const float t = L.t;
@@ -678,7 +686,7 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
     }
     ynew[10] = y[10];
     rk45_eval(ynew, frcp(fmaf(-mdot, t + h, mass0)), c, J, Kn);
-    L.nfev += 6;
+    L.ctl += 1u << 9;   // one more attempt (6 RHS evaluations)
     // ---- error norm ------------------------------------------------------------------------------
     float en = 0.0f;
 #pragma unroll
@@ -703,15 +711,14 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
     const float pw = kSafety * fexp2(-0.1f * flog2(en));
     if (!(en < 1.0f)) {
         L.h_abs *= fmaxf(kMinFactor, pw);
-        L.tries += 1;
+        L.ctl += 1u << 2;   // one more rejection of this step
         return;
     }
     {
         float factor = fminf(kMaxFactor, pw);
-        if (L.tries > 0) factor = fminf(1.0f, factor);
+        if (tries > 0) factor = fminf(1.0f, factor);
         L.h_abs *= factor;
-        L.tries = 0;
-        L.steps += 1;
+        L.ctl &= ~(127u << 2);   // accepted: the next attempt starts a new step
     }
     // ---- terminal event on the accepted sub-step (ivp.py find_active_events / handle_events) ---------
     if (crossing(y[0], ynew[0])) {
@@ -753,7 +760,7 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
             if (i != 10) y[i] = yev[i];
         }
         L.t = t + th * h;
-        L.status = 1;
+        L.ctl = (L.ctl & ~3u) | 2u;   // status 1
     } else {
 #pragma unroll
         for (int i = 0; i < kDyn; ++i) y[i] = ynew[i];
@@ -784,8 +791,8 @@ __device__ __forceinline__ int integrate_rk45(float (&y)[kDyn], float& mass, con
 #pragma unroll 1
     while (rk45_active(L, dt)) rk45_attempt(y, mass, c, J, dt, L);
     rk45_end(y, mass, c, L);
-    nfev = L.nfev;
-    return L.status;
+    nfev = rk45_nfev(L);
+    return rk45_status(L);
 }
 
 // ---- reward (env:317-402) ------------------------------------------------------------------------

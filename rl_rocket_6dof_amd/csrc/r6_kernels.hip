@@ -243,10 +243,13 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #define R6_RK45_WAVES 4    // waves per SIMD the adaptive instances are compiled for (128 registers; round 3: 1 -> 254 registers, two waves)
 #endif
 #ifndef R6_RK45_STASH
-#define R6_RK45_STASH 96   // straggler stash of the adaptive instances (entries per workgroup; see step_kernel)
+#define R6_RK45_STASH 80   // straggler stash of the adaptive instances (entries per workgroup; see step_kernel)
 #endif
 #ifndef R6_RK45_DEFER_DEFAULT
 #define R6_RK45_DEFER_DEFAULT 6   // a wave hands its last <= 6 unfinished lanes to the workgroup's straggler pass (0 = never: every wave follows its slowest lane)
+#endif
+#ifndef R6_RK45_WG_DYNAMIC
+#define R6_RK45_WG_DYNAMIC 0   // A/B: the adaptive instances' waves pull their workgroup's tiles from an LDS counter (tiles take 2-4 attempts: equal lists are unequal work)
 #endif
 #ifndef R6_EULER_WAVES
 #define R6_EULER_WAVES 5   // 90 VGPRs with the register prefetch of the next tile; a budget of 4 waves lets the allocator
@@ -279,9 +282,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // (tests/test_gpu_parity.py::test_rk45_straggler_pass_is_bit_identical).
     constexpr bool kAdaptive = (INTEG == R6_RK45);
     constexpr int kStashCap = kAdaptive ? R6_RK45_STASH : 1;
-    constexpr int kStashWords = 34;   // env | y[13] | mass(t=0) | t, h_abs | K0[9] | nfev, tries, steps | thrust vector, thrust, mdot
+    constexpr int kStashWords = 32;   // env | y[13] | mass(t=0) | t, h_abs | K0[9] | ctl | thrust vector, thrust, mdot
     __shared__ float stash[kAdaptive ? kStashWords : 1][kStashCap];
     __shared__ int stash_count, waves_done;
+    // ... and a parking lot: what a lane needs again only AFTER the integration (v0, the episode counters, the thrust magnitude)
+    // waits in LDS meanwhile -- the attempt loop runs at the 128-register limit of four waves per SIMD, and every register it
+    // does not have is a scratch access per attempt
+    __shared__ float park[kAdaptive ? kWaves : 1][kAdaptive ? 4 : 1][64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -356,11 +363,12 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
 #pragma unroll
         for (int j = 0; j < kDyn; ++j) y[j] = in.y[j];
         float mass = in.mass, ep_ret = in.ep_ret;
-        const float m0 = in.m0, v0 = in.v0, a0 = in.a0, a1 = in.a1, a2 = in.a2;
+        const float m0 = in.m0, a0 = in.a0, a1 = in.a1, a2 = in.a2;
+        float v0 = in.v0;
         uint32_t ep_step = in.ep_step;
 
         // ---- dynamics (sim:69-143) -----------------------------------------------------------------
-        const Control c = make_control_normalised(p, a0, a1, a2);
+        Control c = make_control_normalised(p, a0, a1, a2);
         const Inertia J = make_inertia(m0);
 #ifdef R6_ABLATE_INTEG   // timing-only build: dynamics skipped, inputs kept live
         int status = 0, nfev = 0;
@@ -372,6 +380,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         if constexpr (INTEG == R6_RK45) {
             // integrate_rk45() with the wave-level loop written out: attempt after attempt while any lane integrates; from the
             // third attempt on, a remainder of at most defer_max lanes is handed to the stash instead
+            park[wave][0][lane] = v0;
+            park[wave][1][lane] = ep_ret;
+            park[wave][2][lane] = __uint_as_float(ep_step);
+            park[wave][3][lane] = c.thrust;
+            asm volatile("" ::: "memory");
             Rk45Lane L;
             rk45_begin(y, mass, c, J, p.dt, L);
             int attempts = 0;
@@ -403,14 +416,12 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                                 stash[16][slot] = L.h_abs;
 #pragma unroll
                                 for (int d = 0; d < dp45::D; ++d) stash[17 + d][slot] = L.K0[d];
-                                stash[26][slot] = __int_as_float(L.nfev);
-                                stash[27][slot] = __int_as_float(L.tries);
-                                stash[28][slot] = __int_as_float(L.steps);
-                                stash[29][slot] = c.tbx;
-                                stash[30][slot] = c.tby;
-                                stash[31][slot] = c.tbz;
-                                stash[32][slot] = c.thrust;
-                                stash[33][slot] = c.mdot;
+                                stash[26][slot] = __uint_as_float(L.ctl);
+                                stash[27][slot] = c.tbx;
+                                stash[28][slot] = c.tby;
+                                stash[29][slot] = c.tbz;
+                                stash[30][slot] = park[wave][3][lane];
+                                stash[31][slot] = c.mdot;
                                 deferred = true;
                             }
                         }
@@ -423,8 +434,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                 ++attempts;
             }
             rk45_end(y, mass, c, L);
-            status = L.status;
-            nfev = L.nfev;
+            status = rk45_status(L);
+            nfev = rk45_nfev(L);
+            asm volatile("" ::: "memory");
+            v0 = park[wave][0][lane];
+            ep_ret = park[wave][1][lane];
+            ep_step = __float_as_uint(park[wave][2][lane]);
+            c.thrust = park[wave][3][lane];
         } else {
             status = integrate<INTEG, true, ONE>(y, mass, c, J, p.dt, p.n_substeps);
             nfev = (INTEG == R6_RK4 ? 4 : 1) * (ONE ? 1 : p.n_substeps);
@@ -606,7 +622,10 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // (j / kWaves) * nw + first tile of the workgroup + (j % kWaves).  Measured at N = 2^20: Euler 35.1 -> 34.0 us;
     // the RK4 instances lose with it (38.1 -> 38.7 claimed ahead, 40.0 claimed late: a wave that takes a tile late
     // in the launch finishes it alone) and keep their fixed per-wave lists.
-    constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;   // (the adaptive instances with it: 108.8 -> 122.8 us, round 4)
+    constexpr bool kWgDyn = (R6_WG_DYNAMIC != 0) && kPrefetch;   // (the adaptive instances with it AND the register prefetch it implied: 108.8 -> 122.8 us, round 4)
+    // kWgList: the workgroup-wide tile list without the register prefetch, claimed at the bottom of the rotated loop (adaptive instances, A/B)
+    constexpr bool kWgLate = kAdaptive && (R6_RK45_WG_DYNAMIC != 0) && !kWgDyn;
+    constexpr bool kWgList = kWgDyn || kWgLate;
     const int64_t wg_first = t_first - wave;
     // Order of a wave's (workgroup's) tile list, chosen per launch by the host (launch_step_inst has the numbers).
     // sweep bit 0: the list is walked backwards -- the tile a wave wrote last in the previous launch is the one it reads
@@ -617,20 +636,20 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     // step wrote last is read first while it is still in the 256 MB Infinity Cache.
     const bool rev = (sweep & 1u) != 0u;
     const int n_my = t_first < pool_tiles ? (int)((pool_tiles - 1 - t_first) / nw) + 1 : 0;   // fixed list: tiles of this wave
-    int n_wg = 0;                                                                               // kWgDyn: tiles of this workgroup
-    if constexpr (kWgDyn) {
+    int n_wg = 0;                                                                               // kWgList: tiles of this workgroup
+    if constexpr (kWgList) {
 #pragma unroll 1
         for (int64_t g0 = wg_first; g0 < pool_tiles; g0 += nw) n_wg += (pool_tiles - g0 < kWaves) ? (int)(pool_tiles - g0) : kWaves;
     }
     auto list_tile = [&](int pos) __attribute__((always_inline)) -> int64_t {
-        if constexpr (kWgDyn) {
+        if constexpr (kWgList) {
             const int jj = rev ? n_wg - 1 - pos : pos;
             return wg_first + (int64_t)(jj / kWaves) * nw + (jj % kWaves);
         } else {
             return t_first + (int64_t)(rev ? n_my - 1 - pos : pos) * nw;
         }
     };
-    const int n_pos = kWgDyn ? n_wg : n_my;
+    const int n_pos = kWgList ? n_wg : n_my;
     int wg_jn = -1;
     if constexpr (kEarly) {
         // Rotated tile loop: a tile's inputs are requested at the bottom of the previous iteration, the first tile's
@@ -641,14 +660,15 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         };
         TileIn cur;
         int64_t t = 0;
-        if (n_pos > 0) {
-            t = tile_at(0);
+        int pos = kWgLate ? wave : 0;     // kWgLate: list entries 0..kWaves-1 are the waves' fixed first tiles (wg_next starts behind them)
+        if (pos < n_pos) {
+            t = tile_at(pos);
             if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
             else load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
         }
         __syncthreads();
 #pragma unroll 1
-        for (int pos = 0; pos < n_pos;) {
+        while (pos < n_pos) {
             if (sweep & 4u) {   // A/B: no priority ladder (oldest wave first)
             } else if (tile_no == 0) __builtin_amdgcn_s_setprio(3);
             else if (tile_no == 1) __builtin_amdgcn_s_setprio(2);
@@ -662,7 +682,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                 __builtin_amdgcn_s_waitcnt(0);
                 if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
             }
-            ++pos;
+            if constexpr (kWgLate) {   // the wave that is done first takes the workgroup's next tile
+                int nj = 0;
+                if (lane == 0) nj = atomicAdd(&wg_next, 1);
+                pos = __builtin_amdgcn_readfirstlane(nj);
+            } else {
+                ++pos;
+            }
             if (pos < n_pos) {
                 t = tile_at(pos);
                 if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
@@ -789,16 +815,13 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                     L.h_abs = stash[16][e];
 #pragma unroll
                     for (int d = 0; d < dp45::D; ++d) L.K0[d] = stash[17 + d][e];
-                    L.nfev = __float_as_int(stash[26][e]);
-                    L.tries = __float_as_int(stash[27][e]);
-                    L.steps = __float_as_int(stash[28][e]);
-                    L.status = 0;
+                    L.ctl = __float_as_uint(stash[26][e]);
                     Control c;
-                    c.tbx = stash[29][e];
-                    c.tby = stash[30][e];
-                    c.tbz = stash[31][e];
-                    c.thrust = stash[32][e];
-                    c.mdot = stash[33][e];
+                    c.tbx = stash[27][e];
+                    c.tby = stash[28][e];
+                    c.tbz = stash[29][e];
+                    c.thrust = stash[30][e];
+                    c.mdot = stash[31][e];
                     const float m0 = bb.epconst[i];
                     float v0 = 0.0f;
                     if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = bb.epconst[ld + i];
@@ -814,7 +837,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
                         if (rk45_active(L, p.dt)) rk45_attempt(y, mass, c, J, p.dt, L);
                     }
                     rk45_end(y, mass, c, L);
-                    const int status = L.status, nfev = L.nfev;
+                    const int status = rk45_status(L), nfev = rk45_nfev(L);
                     // termination, reward, fused wrappers, outputs: process_tile's sequence, operation for operation
                     const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
                     bool done = (status != 0) || bnd, truncated = false;
