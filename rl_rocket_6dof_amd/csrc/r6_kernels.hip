@@ -243,7 +243,7 @@ __device__ __forceinline__ void load_tile(const R6Buffers& b, bool has_ep, int64
 #define R6_RK45_WAVES 4    // waves per SIMD the adaptive instances are compiled for (128 registers; round 3: 1 -> 254 registers, two waves)
 #endif
 #ifndef R6_RK45_STASH
-#define R6_RK45_STASH 80   // straggler stash of the adaptive instances (entries per workgroup; see step_kernel)
+#define R6_RK45_STASH 12   // guest list of the adaptive instances (entries per WAVE; see step_kernel)
 #endif
 #ifndef R6_RK45_DEFER_DEFAULT
 #define R6_RK45_DEFER_DEFAULT 6   // a wave hands its last <= 6 unfinished lanes to the workgroup's straggler pass (0 = never: every wave follows its slowest lane)
@@ -272,19 +272,28 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     __shared__ int rq_count;
     __shared__ int wg_next;
     __shared__ stat_t blk_stats[R6_NUM_STATS];
-    // Adaptive instances: the straggler stash.  scipy's RK45 needs one step for 39 % of the env steps, two for 60 %, three or four
-    // for 0.8 % (golden G3) -- and a wave follows its slowest lane: 2.46 attempts per 64-env tile against 1.63 per lane (round 4),
-    // with 0.5 lanes per wave alive in the attempts beyond the second, and launch times that follow the unluckiest wave.  A wave
-    // therefore stops after its second attempt when at most `defer_max` lanes are still integrating: their state goes to this
-    // per-workgroup stash (structure of arrays, one column per env) and the wave finishes its tile without them.  The LAST wave
-    // of the workgroup to leave the tile loop integrates the stash densely -- one pass for the whole workgroup -- and
-    // writes those envs' outputs itself.  Same arithmetic per lane, whoever runs it: bit for bit the results without the stash
-    // (tests/test_gpu_parity.py::test_rk45_straggler_pass_is_bit_identical).
+    // Adaptive instances: guests.  scipy's RK45 needs one step for 32 % of the env steps of the bench's steady state, two for 66.5 %,
+    // three or four for 1.4 % (gpurun_out/r5_rk45_attempts.json) -- and a wave follows its slowest lane: 2.74 attempts per 64-env tile
+    // against 1.70 per lane, 0.9 lanes per wave alive in the attempts beyond the second.  A wave therefore stops after its second
+    // attempt when at most `defer_max` lanes are still integrating: their state goes to the wave's own guest list in LDS
+    // (structure of arrays, one column per env) and the wave finishes its tile without them.  In the attempts of its LATER tiles the
+    // lanes that have nothing to integrate any more (a third of them in every second attempt) lend themselves to the guests: such a
+    // lane parks its own finished state in LDS, runs the attempt on a guest's, puts the guest back and takes its own state
+    // again.  A guest thus costs no wave-level attempt of its own.  After its last tile (where nothing is handed over) the wave
+    // finishes whatever guest still integrates and does for all of them what process_tile does for a tile's lanes, with
+    // per-lane addresses.  Nothing is shared between waves; same arithmetic per env, whoever's lane runs it: bit for bit the
+    // results without the hand-over (tests/test_gpu_parity.py::test_rk45_straggler_pass_is_bit_identical).
+    // (Round 5 first built the per-WORKGROUP form the round-4 review asked for -- one stash, drained densely by the last wave
+    // to leave the tile loop: 16 % fewer vector instructions and 114.3 -> 109.6 us only: the pass is two attempts and a reward
+    // phase of ONE wave alone on its SIMD, latency-bound at ~3 ns per instruction, ~12 us at the end of every workgroup while
+    // its other waves wait at the barrier (SQ_WAIT_ANY +29 %; gpurun_out/pmc_rk45_r5/summary.json; code at commit 8b63f76).)
     constexpr bool kAdaptive = (INTEG == R6_RK45);
-    constexpr int kStashCap = kAdaptive ? R6_RK45_STASH : 1;
-    constexpr int kStashWords = 32;   // env | y[13] | mass(t=0) | t, h_abs | K0[9] | ctl | thrust vector, thrust, mdot
-    __shared__ float stash[kAdaptive ? kStashWords : 1][kStashCap];
-    __shared__ int stash_count, waves_done;
+    constexpr int kG = kAdaptive ? R6_RK45_STASH : 1;
+    static_assert(kG <= 32, "the pending mask is one 32-bit word");
+    constexpr int kGuestWords = 34;   // env | y[13] | mass(t=0) | t, h_abs | K0[9] | ctl | thrust vector, thrust, mdot | 1/Jt, Jx-Jt
+    constexpr int kSaveWords = 23;    // a hosting lane's own (finished) state: y[13] | mass(t=0) | t | ctl | control[5] | inertia[2]
+    __shared__ float gst[kAdaptive ? kWaves : 1][kAdaptive ? kGuestWords : 1][kG];
+    __shared__ float sv[kAdaptive ? kWaves : 1][kAdaptive ? kSaveWords : 1][kG];
     // ... and a parking lot: what a lane needs again only AFTER the integration (v0, the episode counters, the thrust magnitude)
     // waits in LDS meanwhile -- the attempt loop runs at the 128-register limit of four waves per SIMD, and every register it
     // does not have is a scratch access per attempt
@@ -295,6 +304,8 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> scalar tile arithmetic
     float* tile = tiles[wave];
     const int defer_max = kAdaptive ? (int)((sweep >> 8) & 0xffu) : 0;
+    int g_n = 0;             // adaptive instances: entries of this wave's guest list (wave-uniform)
+    uint32_t g_pend = 0u;    // ... and which of them still integrate
     const int64_t n = b.n;
     const int64_t n_tiles = (n + 63) >> 6;
     // XCD-aware tile split.  Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8 = XCC_ID, checked with
@@ -338,8 +349,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     if (tid == 0) {
         rq_count = 0;
         wg_next = kWaves;   // list entries 0..kWaves-1 are the waves' fixed first tiles
-        stash_count = 0;
-        waves_done = 0;
     }
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
     if (tid < R6_STATE_DIM) {  // per-lane read of the kernarg segment (R6Params is argument 0)
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     if constexpr (!kEarly) __syncthreads();
 
     // One 64-env tile.  FULL = all 64 lanes are live (every tile but possibly the last one).
-    auto process_tile = [&](const int64_t e0, const TileIn& in, auto full_c) __attribute__((always_inline)) {
+    auto process_tile = [&](const int64_t e0, const TileIn& in, auto full_c, const bool tile_may_defer) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
         bool overflow = false;       // this lane's finished episode did not fit into the reset queue
         const int64_t rem = n - e0;  // envs from the tile's start to the end of the shard (> 0)
@@ -378,59 +387,129 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         int nfev = 0;
         int status;
         if constexpr (INTEG == R6_RK45) {
-            // integrate_rk45() with the wave-level loop written out: attempt after attempt while any lane integrates; from the
-            // third attempt on, a remainder of at most defer_max lanes is handed to the stash instead
+            // integrate_rk45() with the wave-level loop written out: attempt after attempt while any lane of the tile integrates; from the
+            // third attempt on, a remainder of at most defer_max lanes becomes guests (not in a wave's last tile: nobody would host them)
             park[wave][0][lane] = v0;
             park[wave][1][lane] = ep_ret;
             park[wave][2][lane] = __uint_as_float(ep_step);
             park[wave][3][lane] = c.thrust;
             asm volatile("" ::: "memory");
             Rk45Lane L;
-            rk45_begin(y, mass, c, J, p.dt, L);
+            Inertia Jl = J;          // (a hosting lane runs a guest's inertia for one attempt)
+            rk45_begin(y, mass, c, Jl, p.dt, L);
             int attempts = 0;
-            bool may_defer = defer_max > 0;
+            float(*const gl)[kG] = gst[wave];
+            float(*const sl)[kG] = sv[wave];
 #pragma unroll 1
             for (;;) {
-                const bool active = rk45_active(L, p.dt) && !deferred;
+                const bool active = rk45_active(L, p.dt);
                 const uint64_t m = __ballot(active);
                 if (m == 0ull) break;
                 // (padding lanes of the shard's last tile integrate a benign state like everybody else, but nobody needs their
-                //  result: they are dropped at the hand-over and never take a stash slot -- a slot without a writer would hand the
-                //  pass an env index that was never written)
+                //  result: they are dropped at the hand-over and never take a slot)
                 const uint64_t ml = FULL ? m : __ballot(active && lane_live);
                 const int cnt = __popcll(ml);
-                if (may_defer && attempts >= 2 && cnt <= defer_max) {
-                    if (cnt > 0) {
-                        const int first = __builtin_ctzll(ml);
-                        int base = 0;
-                        if (lane == first) base = atomicAdd(&stash_count, cnt);
-                        base = __builtin_amdgcn_readlane(base, first);
-                        if (active && lane_live) {
-                            const int slot = base + __popcll(ml & ((1ull << lane) - 1ull));
-                            if (slot < kStashCap) {
-                                stash[0][slot] = __int_as_float((int)(e0 + lane));
+                if (tile_may_defer && attempts >= 2 && cnt <= defer_max && g_n + cnt <= kG) {
+                    if (active && lane_live) {
+                        const int slot = g_n + __popcll(ml & ((1ull << lane) - 1ull));
+                        gl[0][slot] = __int_as_float((int)(e0 + lane));
 #pragma unroll
-                                for (int j = 0; j < kDyn; ++j) stash[1 + j][slot] = y[j];
-                                stash[14][slot] = mass;
-                                stash[15][slot] = L.t;
-                                stash[16][slot] = L.h_abs;
+                        for (int j = 0; j < kDyn; ++j) gl[1 + j][slot] = y[j];
+                        gl[14][slot] = mass;
+                        gl[15][slot] = L.t;
+                        gl[16][slot] = L.h_abs;
 #pragma unroll
-                                for (int d = 0; d < dp45::D; ++d) stash[17 + d][slot] = L.K0[d];
-                                stash[26][slot] = __uint_as_float(L.ctl);
-                                stash[27][slot] = c.tbx;
-                                stash[28][slot] = c.tby;
-                                stash[29][slot] = c.tbz;
-                                stash[30][slot] = park[wave][3][lane];
-                                stash[31][slot] = c.mdot;
-                                deferred = true;
-                            }
-                        }
+                        for (int d = 0; d < dp45::D; ++d) gl[17 + d][slot] = L.K0[d];
+                        gl[26][slot] = __uint_as_float(L.ctl);
+                        gl[27][slot] = c.tbx;
+                        gl[28][slot] = c.tby;
+                        gl[29][slot] = c.tbz;
+                        gl[30][slot] = park[wave][3][lane];
+                        gl[31][slot] = c.mdot;
+                        gl[32][slot] = Jl.inv_jt;
+                        gl[33][slot] = Jl.jdiff;
                     }
-                    if (active && !lane_live) deferred = true;
-                    may_defer = false;   // one hand-over per tile; lanes that found the stash full go on in this wave
-                    continue;
+                    if (active) deferred = true;
+                    g_pend |= (cnt > 0 ? ((1u << cnt) - 1u) : 0u) << g_n;
+                    g_n += cnt;
+                    break;
                 }
-                if (active) rk45_attempt(y, mass, c, J, p.dt, L);
+                // ---- guests: pending entry k of the list rides in the k-th lane of this attempt that has nothing of its own to do ----
+                int my_entry = -1;
+                const uint32_t pend0 = g_pend;
+                if (pend0 != 0u) {
+                    uint32_t pe = pend0;
+                    uint64_t im = ~m;
+                    while (pe != 0u && im != 0ull) {
+                        const int e = __builtin_ctz(pe), l = __builtin_ctzll(im);
+                        pe &= pe - 1u;
+                        im &= im - 1ull;
+                        if (lane == l) my_entry = e;
+                    }
+                    if (my_entry >= 0) {
+#pragma unroll
+                        for (int j = 0; j < kDyn; ++j) sl[j][my_entry] = y[j];
+                        sl[13][my_entry] = mass;
+                        sl[14][my_entry] = L.t;
+                        sl[15][my_entry] = __uint_as_float(L.ctl);
+                        sl[16][my_entry] = c.tbx;
+                        sl[17][my_entry] = c.tby;
+                        sl[18][my_entry] = c.tbz;
+                        sl[19][my_entry] = c.thrust;
+                        sl[20][my_entry] = c.mdot;
+                        sl[21][my_entry] = Jl.inv_jt;
+                        sl[22][my_entry] = Jl.jdiff;
+#pragma unroll
+                        for (int j = 0; j < kDyn; ++j) y[j] = gl[1 + j][my_entry];
+                        mass = gl[14][my_entry];
+                        L.t = gl[15][my_entry];
+                        L.h_abs = gl[16][my_entry];
+#pragma unroll
+                        for (int d = 0; d < dp45::D; ++d) L.K0[d] = gl[17 + d][my_entry];
+                        L.ctl = __float_as_uint(gl[26][my_entry]);
+                        c.tbx = gl[27][my_entry];
+                        c.tby = gl[28][my_entry];
+                        c.tbz = gl[29][my_entry];
+                        c.thrust = gl[30][my_entry];
+                        c.mdot = gl[31][my_entry];
+                        Jl.inv_jt = gl[32][my_entry];
+                        Jl.jdiff = gl[33][my_entry];
+                    }
+                }
+                if (active || my_entry >= 0) rk45_attempt(y, mass, c, Jl, p.dt, L);
+                if (pend0 != 0u) {
+                    const uint64_t fin = __ballot(my_entry >= 0 && !rk45_active(L, p.dt));
+                    if (my_entry >= 0) {
+#pragma unroll
+                        for (int j = 0; j < kDyn; ++j) gl[1 + j][my_entry] = y[j];
+                        gl[15][my_entry] = L.t;
+                        gl[16][my_entry] = L.h_abs;
+#pragma unroll
+                        for (int d = 0; d < dp45::D; ++d) gl[17 + d][my_entry] = L.K0[d];
+                        gl[26][my_entry] = __uint_as_float(L.ctl);
+#pragma unroll
+                        for (int j = 0; j < kDyn; ++j) y[j] = sl[j][my_entry];
+                        mass = sl[13][my_entry];
+                        L.t = sl[14][my_entry];
+                        L.ctl = __float_as_uint(sl[15][my_entry]);
+                        c.tbx = sl[16][my_entry];
+                        c.tby = sl[17][my_entry];
+                        c.tbz = sl[18][my_entry];
+                        c.thrust = sl[19][my_entry];
+                        c.mdot = sl[20][my_entry];
+                        Jl.inv_jt = sl[21][my_entry];
+                        Jl.jdiff = sl[22][my_entry];
+                    }
+                    // the guests that arrived leave the pending set: the pairing above again, on scalars
+                    uint32_t pe = pend0;
+                    uint64_t im = ~m;
+                    while (pe != 0u && im != 0ull) {
+                        const int e = __builtin_ctz(pe), l = __builtin_ctzll(im);
+                        pe &= pe - 1u;
+                        im &= im - 1ull;
+                        if ((fin >> l) & 1ull) g_pend &= ~(1u << e);
+                    }
+                }
                 ++attempts;
             }
             rk45_end(y, mass, c, L);
@@ -676,8 +755,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             else __builtin_amdgcn_s_setprio(0);
             ++tile_no;
             bool overflow;
-            if (t < n_full) overflow = process_tile(t * 64, cur, std::true_type{});
-            else overflow = process_tile(t * 64, cur, std::false_type{});
+            // a wave's stragglers ride along in its LATER tiles: none are handed over in its last one (with the workgroup-wide list
+            // a wave does not know its last tile: the last kWaves entries count as such)
+            const bool may_defer = defer_max > 0 && (kWgLate ? (pos + kWaves < n_pos) : (pos + 1 < n_pos));
+            if (t < n_full) overflow = process_tile(t * 64, cur, std::true_type{}, may_defer);
+            else overflow = process_tile(t * 64, cur, std::false_type{}, may_defer);
             if (__builtin_expect(__any(overflow), 0)) {
                 __builtin_amdgcn_s_waitcnt(0);
                 if (overflow) reset_env_global<OD>(load_params(), load_buffers(), t * 64 + lane, seed, step_index, env_offset);
@@ -738,7 +820,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             __builtin_amdgcn_s_waitcnt(0);
             const uint32_t tr_b = (uint32_t)wall_clock64();
 #endif
-            overflow = process_tile(t * 64, cur, std::true_type{});
+            overflow = process_tile(t * 64, cur, std::true_type{}, false);
 #ifdef R6_TRACE
             const uint32_t tr_c = (uint32_t)wall_clock64();
             __builtin_amdgcn_s_waitcnt(0);
@@ -759,7 +841,7 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         } else {
             have_nxt = false;
             load_tile<SHAPING, false>(b, has_ep, t * 64, lane, cur);
-            overflow = process_tile(t * 64, cur, std::false_type{});
+            overflow = process_tile(t * 64, cur, std::false_type{}, false);
         }
         if (__builtin_expect(__any(overflow), 0)) {
             // Reset queue full (mass termination, e.g. the first landing wave of envs started in lockstep):
@@ -783,124 +865,112 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     }   // !kEarly
     __builtin_amdgcn_s_setprio(0);
 
-    // ---- adaptive instances: the straggler pass (see `stash` above).  The last wave of the workgroup to get here integrates every
-    //      env the workgroup's waves have handed over, 64 at a time, and does for them what process_tile does for a tile's lanes --
-    //      with per-lane addresses, since these envs come from all over the workgroup's tiles. ----------------------------------
+    // ---- adaptive instances: the wave's guests (see `gst` above).  Whoever still integrates is finished here (rare: a guest rides
+    //      in every attempt after its hand-over that has a free lane), then every guest gets what process_tile gives a tile's
+    //      lanes -- termination, reward, outputs, episode end -- with per-lane addresses. ----------------------------------
     if constexpr (kAdaptive) {
-        if (defer_max > 0) {
-            // this wave's tile stores are acknowledged before it reports in: the pass overwrites rows (the observation block of a
-            // tile is stored whole, a deferred lane's row included) and must come second
+        if (g_n > 0) {
+            // the observation block of a tile is stored whole, a guest's row included: those stores come first
             __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            int arrived = 0;
-            if (lane == 0) arrived = atomicAdd(&waves_done, 1);
-            arrived = __builtin_amdgcn_readfirstlane(arrived);
-            if (arrived == kWaves - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const int n_in = __builtin_amdgcn_readfirstlane(__atomic_load_n(&stash_count, __ATOMIC_RELAXED));
-                const int n_s = n_in < kStashCap ? n_in : kStashCap;
+            const bool valid = lane < g_n;
+            const int e = valid ? lane : 0;
+            float(*const gl)[kG] = gst[wave];
+            const R6Buffers bb = load_buffers();
+            const int64_t ld = bb.ld;
+            const int64_t i = (int64_t)__float_as_int(gl[0][e]);
+            float y[kDyn];
+#pragma unroll
+            for (int j = 0; j < kDyn; ++j) y[j] = gl[1 + j][e];
+            float mass = gl[14][e];
+            Rk45Lane L;
+            L.t = valid ? gl[15][e] : p.dt;    // an idle lane: nothing to integrate
+            L.h_abs = gl[16][e];
+#pragma unroll
+            for (int d = 0; d < dp45::D; ++d) L.K0[d] = gl[17 + d][e];
+            L.ctl = __float_as_uint(gl[26][e]);
+            Control c;
+            c.tbx = gl[27][e];
+            c.tby = gl[28][e];
+            c.tbz = gl[29][e];
+            c.thrust = gl[30][e];
+            c.mdot = gl[31][e];
+            Inertia J;
+            J.inv_jt = gl[32][e];
+            J.jdiff = gl[33][e];
+            float v0 = 0.0f;
+            if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = bb.epconst[ld + i];
+            uint32_t ep_step = 0u;
+            float ep_ret = 0.0f;
+            if (has_ep) {
+                ep_step = bb.ep_step[i];
+                ep_ret = bb.ep_return[i];
+            }
 #pragma unroll 1
-                for (int base = 0; base < n_s; base += 64) {
-                    const bool valid = base + lane < n_s;
-                    const int e = valid ? base + lane : 0;
-                    const R6Buffers bb = load_buffers();
-                    const int64_t ld = bb.ld;
-                    const int64_t i = (int64_t)__float_as_int(stash[0][e]);
-                    float y[kDyn];
+            while (__any(rk45_active(L, p.dt))) {
+                if (rk45_active(L, p.dt)) rk45_attempt(y, mass, c, J, p.dt, L);
+            }
+            rk45_end(y, mass, c, L);
+            const int status = rk45_status(L), nfev = rk45_nfev(L);
+            // termination, reward, fused wrappers, outputs: process_tile's sequence, operation for operation
+            const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
+            bool done = (status != 0) || bnd, truncated = false;
+            RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
+            const bool landed = rw.landed;
+            float rew = finalize_reward(p, rw, bnd, fmaf(2.0f * c.thrust, frcp(p.max_thrust), -1.0f), y);
+            if (valid && bb.terms) {
 #pragma unroll
-                    for (int j = 0; j < kDyn; ++j) y[j] = stash[1 + j][e];
-                    float mass = stash[14][e];
-                    Rk45Lane L;
-                    L.t = valid ? stash[15][e] : p.dt;    // an idle lane of the pass: nothing to integrate
-                    L.h_abs = stash[16][e];
+                for (int q = 0; q < R6_NUM_TERMS; ++q) bb.terms[q * ld + i] = rw.terms[q];
+            }
+            if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
+            ep_step += 1u;
+            ep_ret += rew;
+            if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
+                truncated = !done;
+                done = true;
+            }
+            bool overflow = false;
+            if (valid) {
+                bb.reward[i] = rew;
+                bb.done[i] = done ? 1 : 0;
 #pragma unroll
-                    for (int d = 0; d < dp45::D; ++d) L.K0[d] = stash[17 + d][e];
-                    L.ctl = __float_as_uint(stash[26][e]);
-                    Control c;
-                    c.tbx = stash[27][e];
-                    c.tby = stash[28][e];
-                    c.tbz = stash[29][e];
-                    c.thrust = stash[30][e];
-                    c.mdot = stash[31][e];
-                    const float m0 = bb.epconst[i];
-                    float v0 = 0.0f;
-                    if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = bb.epconst[ld + i];
-                    uint32_t ep_step = 0u;
-                    float ep_ret = 0.0f;
-                    if (has_ep) {
-                        ep_step = bb.ep_step[i];
-                        ep_ret = bb.ep_return[i];
-                    }
-                    const Inertia J = make_inertia(m0);
-#pragma unroll 1
-                    while (__any(rk45_active(L, p.dt))) {
-                        if (rk45_active(L, p.dt)) rk45_attempt(y, mass, c, J, p.dt, L);
-                    }
-                    rk45_end(y, mass, c, L);
-                    const int status = rk45_status(L), nfev = rk45_nfev(L);
-                    // termination, reward, fused wrappers, outputs: process_tile's sequence, operation for operation
-                    const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
-                    bool done = (status != 0) || bnd, truncated = false;
-                    RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
-                    const bool landed = rw.landed;
-                    float rew = finalize_reward(p, rw, bnd, fmaf(2.0f * c.thrust, frcp(p.max_thrust), -1.0f), y);
-                    if (valid && bb.terms) {
+                for (int j = 0; j < kDyn; ++j) bb.state[j * ld + i] = y[j];
+                bb.state[kDyn * ld + i] = mass;
+                if (has_ep) {
+                    bb.ep_step[i] = ep_step;
+                    bb.ep_return[i] = ep_ret;
+                }
+                if (bb.flags)
+                    bb.flags[i] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
+                if (bb.nfev) bb.nfev[i] = (uint8_t)(nfev > 255 ? 255 : nfev);
+                float ob[OD];
 #pragma unroll
-                        for (int q = 0; q < R6_NUM_TERMS; ++q) bb.terms[q * ld + i] = rw.terms[q];
-                    }
-                    if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
-                    ep_step += 1u;
-                    ep_ret += rew;
-                    if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
-                        truncated = !done;
-                        done = true;
-                    }
-                    bool overflow = false;
-                    if (valid) {
-                        bb.reward[i] = rew;
-                        bb.done[i] = done ? 1 : 0;
+                for (int j = 0; j < kDyn; ++j) {
+                    if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
+                }
+                if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
 #pragma unroll
-                        for (int j = 0; j < kDyn; ++j) bb.state[j * ld + i] = y[j];
-                        bb.state[kDyn * ld + i] = mass;
-                        if (has_ep) {
-                            bb.ep_step[i] = ep_step;
-                            bb.ep_return[i] = ep_ret;
+                for (int j = 0; j < OD; ++j) bb.obs[i * OD + j] = ob[j];
+                if (done) {
+                    if (bb.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
+                    if (p.auto_reset) {
+                        if (bb.final_obs) {
+#pragma unroll
+                            for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = ob[j];
                         }
-                        if (bb.flags)
-                            bb.flags[i] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
-                        if (bb.nfev) bb.nfev[i] = (uint8_t)(nfev > 255 ? 255 : nfev);
-                        float ob[OD];
-#pragma unroll
-                        for (int j = 0; j < kDyn; ++j) {
-                            if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
-                        }
-                        if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
-#pragma unroll
-                        for (int j = 0; j < OD; ++j) bb.obs[i * OD + j] = ob[j];
-                        if (done) {
-                            if (bb.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
-                            if (p.auto_reset) {
-                                if (bb.final_obs) {
-#pragma unroll
-                                    for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = ob[j];
-                                }
-                                if (bb.fin_return) bb.fin_return[i] = ep_ret;
-                                if (bb.fin_length) bb.fin_length[i] = ep_step;
-                                const int slot = atomicAdd(&rq_count, 1);
-                                if (slot < kResetQueueCap) rq[slot] = (int)i;
-                                else overflow = true;
-                            }
-                        }
-                    }
-                    if (__builtin_expect(__any(overflow), 0)) {
-                        __builtin_amdgcn_s_waitcnt(0);
-                        if (overflow) reset_env_global<OD>(load_params(), bb, i, seed, step_index, env_offset);
+                        if (bb.fin_return) bb.fin_return[i] = ep_ret;
+                        if (bb.fin_length) bb.fin_length[i] = ep_step;
+                        const int slot = atomicAdd(&rq_count, 1);
+                        if (slot < kResetQueueCap) rq[slot] = (int)i;
+                        else overflow = true;
                     }
                 }
             }
+            if (__builtin_expect(__any(overflow), 0)) {
+                __builtin_amdgcn_s_waitcnt(0);
+                if (overflow) reset_env_global<OD>(load_params(), bb, i, seed, step_index, env_offset);
+            }
         }
     }
-
 #ifdef R6_PHASE_TIMING
     const uint64_t pt1 = wall_clock64();
 #endif
