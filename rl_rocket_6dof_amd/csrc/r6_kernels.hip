@@ -666,6 +666,143 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         return overflow;
     };
 
+    // ---- adaptive instances: what becomes of a wave's guests (see `gst` above).  Every guest that has arrived gets what process_tile
+    //      gives a tile's lanes -- termination, reward, outputs, episode end -- with per-lane addresses, and leaves the list.
+    //      final: whoever still integrates is finished first (rare: a guest rides in every attempt after its hand-over that has
+    //      a free lane); otherwise (the list is nearly full in the middle of the tile loop) the guests still under way move to the
+    //      front of the list and stay. ----------------------------------------------------------------------------------------
+    auto flush_guests = [&](const bool final) __attribute__((always_inline)) {
+        if constexpr (kAdaptive) {
+            if (g_n > 0) {
+                // the observation block of a tile is stored whole, a guest's row included: those stores come first
+                __builtin_amdgcn_s_waitcnt(0);
+                const bool mine = lane < g_n;
+                const int e = mine ? lane : 0;
+                float(*const gl)[kG] = gst[wave];
+                const R6Buffers bb = load_buffers();
+                const int64_t ld = bb.ld;
+                const int64_t i = (int64_t)__float_as_int(gl[0][e]);
+                float y[kDyn];
+#pragma unroll
+                for (int j = 0; j < kDyn; ++j) y[j] = gl[1 + j][e];
+                float mass = gl[14][e];
+                Rk45Lane L;
+                L.t = mine ? gl[15][e] : p.dt;    // an idle lane: nothing to integrate
+                L.h_abs = gl[16][e];
+#pragma unroll
+                for (int d = 0; d < dp45::D; ++d) L.K0[d] = gl[17 + d][e];
+                L.ctl = __float_as_uint(gl[26][e]);
+                Control c;
+                c.tbx = gl[27][e];
+                c.tby = gl[28][e];
+                c.tbz = gl[29][e];
+                c.thrust = gl[30][e];
+                c.mdot = gl[31][e];
+                Inertia J;
+                J.inv_jt = gl[32][e];
+                J.jdiff = gl[33][e];
+                if (final) {
+#pragma unroll 1
+                    while (__any(rk45_active(L, p.dt))) {
+                        if (rk45_active(L, p.dt)) rk45_attempt(y, mass, c, J, p.dt, L);
+                    }
+                }
+                const bool under_way = mine && rk45_active(L, p.dt);       // (never with `final`)
+                const bool valid = mine && !under_way;
+                const uint64_t keep = __ballot(under_way);
+                if (under_way) {   // to the front of the list (every lane has read its entry before anybody writes)
+                    const int slot = __popcll(keep & ((1ull << lane) - 1ull));
+                    gl[0][slot] = __int_as_float((int)i);
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) gl[1 + j][slot] = y[j];
+                    gl[14][slot] = mass;
+                    gl[15][slot] = L.t;
+                    gl[16][slot] = L.h_abs;
+#pragma unroll
+                    for (int d = 0; d < dp45::D; ++d) gl[17 + d][slot] = L.K0[d];
+                    gl[26][slot] = __uint_as_float(L.ctl);
+                    gl[27][slot] = c.tbx;
+                    gl[28][slot] = c.tby;
+                    gl[29][slot] = c.tbz;
+                    gl[30][slot] = c.thrust;
+                    gl[31][slot] = c.mdot;
+                    gl[32][slot] = J.inv_jt;
+                    gl[33][slot] = J.jdiff;
+                }
+                g_n = __popcll(keep);
+                g_pend = g_n > 0 ? ((1u << g_n) - 1u) : 0u;
+                float v0 = 0.0f;
+                if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = bb.epconst[ld + i];
+                uint32_t ep_step = 0u;
+                float ep_ret = 0.0f;
+                if (has_ep) {
+                    ep_step = bb.ep_step[i];
+                    ep_ret = bb.ep_return[i];
+                }
+                rk45_end(y, mass, c, L);
+                const int status = rk45_status(L), nfev = rk45_nfev(L);
+                // termination, reward, fused wrappers, outputs: process_tile's sequence, operation for operation
+                const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
+                bool done = (status != 0) || bnd, truncated = false;
+                RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
+                const bool landed = rw.landed;
+                float rew = finalize_reward(p, rw, bnd, fmaf(2.0f * c.thrust, frcp(p.max_thrust), -1.0f), y);
+                if (valid && bb.terms) {
+#pragma unroll
+                    for (int q = 0; q < R6_NUM_TERMS; ++q) bb.terms[q * ld + i] = rw.terms[q];
+                }
+                if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
+                ep_step += 1u;
+                ep_ret += rew;
+                if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
+                    truncated = !done;
+                    done = true;
+                }
+                bool overflow = false;
+                if (valid) {
+                    bb.reward[i] = rew;
+                    bb.done[i] = done ? 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) bb.state[j * ld + i] = y[j];
+                    bb.state[kDyn * ld + i] = mass;
+                    if (has_ep) {
+                        bb.ep_step[i] = ep_step;
+                        bb.ep_return[i] = ep_ret;
+                    }
+                    if (bb.flags)
+                        bb.flags[i] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
+                    if (bb.nfev) bb.nfev[i] = (uint8_t)(nfev > 255 ? 255 : nfev);
+                    float ob[OD];
+#pragma unroll
+                    for (int j = 0; j < kDyn; ++j) {
+                        if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
+                    }
+                    if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
+#pragma unroll
+                    for (int j = 0; j < OD; ++j) bb.obs[i * OD + j] = ob[j];
+                    if (done) {
+                        if (bb.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
+                        if (p.auto_reset) {
+                            if (bb.final_obs) {
+#pragma unroll
+                                for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = ob[j];
+                            }
+                            if (bb.fin_return) bb.fin_return[i] = ep_ret;
+                            if (bb.fin_length) bb.fin_length[i] = ep_step;
+                            const int slot = atomicAdd(&rq_count, 1);
+                            if (slot < kResetQueueCap) rq[slot] = (int)i;
+                            else overflow = true;
+                        }
+                    }
+                }
+                if (__builtin_expect(__any(overflow), 0)) {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (overflow) reset_env_global<OD>(load_params(), bb, i, seed, step_index, env_offset);
+                }
+            }
+        }
+    };
+
     // Tile loop.  (Measured alternatives that did not pay at N = 2^20, where the loop is VALU-bound:
     // register prefetch of the next tile -- +30 VGPRs, one wave per SIMD less, no gain; deferring
     // ground-event envs to the dense pass -- its serial tail per workgroup costs more than the
@@ -771,6 +908,10 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
             } else {
                 ++pos;
             }
+            if constexpr (kAdaptive) {   // the guests: all of them after the wave's last tile, the arrived ones when the list runs out of room
+                const bool last = !(pos < n_pos);
+                if (last || g_n + defer_max > kG) flush_guests(last);
+            }
             if (pos < n_pos) {
                 t = tile_at(pos);
                 if (t < n_full) load_tile<SHAPING, true>(b, has_ep, t * 64, lane, cur, tile);
@@ -865,112 +1006,6 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
     }   // !kEarly
     __builtin_amdgcn_s_setprio(0);
 
-    // ---- adaptive instances: the wave's guests (see `gst` above).  Whoever still integrates is finished here (rare: a guest rides
-    //      in every attempt after its hand-over that has a free lane), then every guest gets what process_tile gives a tile's
-    //      lanes -- termination, reward, outputs, episode end -- with per-lane addresses. ----------------------------------
-    if constexpr (kAdaptive) {
-        if (g_n > 0) {
-            // the observation block of a tile is stored whole, a guest's row included: those stores come first
-            __builtin_amdgcn_s_waitcnt(0);
-            const bool valid = lane < g_n;
-            const int e = valid ? lane : 0;
-            float(*const gl)[kG] = gst[wave];
-            const R6Buffers bb = load_buffers();
-            const int64_t ld = bb.ld;
-            const int64_t i = (int64_t)__float_as_int(gl[0][e]);
-            float y[kDyn];
-#pragma unroll
-            for (int j = 0; j < kDyn; ++j) y[j] = gl[1 + j][e];
-            float mass = gl[14][e];
-            Rk45Lane L;
-            L.t = valid ? gl[15][e] : p.dt;    // an idle lane: nothing to integrate
-            L.h_abs = gl[16][e];
-#pragma unroll
-            for (int d = 0; d < dp45::D; ++d) L.K0[d] = gl[17 + d][e];
-            L.ctl = __float_as_uint(gl[26][e]);
-            Control c;
-            c.tbx = gl[27][e];
-            c.tby = gl[28][e];
-            c.tbz = gl[29][e];
-            c.thrust = gl[30][e];
-            c.mdot = gl[31][e];
-            Inertia J;
-            J.inv_jt = gl[32][e];
-            J.jdiff = gl[33][e];
-            float v0 = 0.0f;
-            if constexpr (SHAPING == R6_SHAPING_VELOCITY) v0 = bb.epconst[ld + i];
-            uint32_t ep_step = 0u;
-            float ep_ret = 0.0f;
-            if (has_ep) {
-                ep_step = bb.ep_step[i];
-                ep_ret = bb.ep_return[i];
-            }
-#pragma unroll 1
-            while (__any(rk45_active(L, p.dt))) {
-                if (rk45_active(L, p.dt)) rk45_attempt(y, mass, c, J, p.dt, L);
-            }
-            rk45_end(y, mass, c, L);
-            const int status = rk45_status(L), nfev = rk45_nfev(L);
-            // termination, reward, fused wrappers, outputs: process_tile's sequence, operation for operation
-            const bool bnd = bounds_violation(p, y[0], y[1], y[2]);
-            bool done = (status != 0) || bnd, truncated = false;
-            RewardOut rw = reward<SHAPING>(p, y, mass, c, v0);
-            const bool landed = rw.landed;
-            float rew = finalize_reward(p, rw, bnd, fmaf(2.0f * c.thrust, frcp(p.max_thrust), -1.0f), y);
-            if (valid && bb.terms) {
-#pragma unroll
-                for (int q = 0; q < R6_NUM_TERMS; ++q) bb.terms[q * ld + i] = rw.terms[q];
-            }
-            if (p.clip_reward) rew = fminf(fmaxf(rew, p.clip_lo), p.clip_hi);
-            ep_step += 1u;
-            ep_ret += rew;
-            if (p.max_episode_steps > 0 && ep_step >= (uint32_t)p.max_episode_steps) {
-                truncated = !done;
-                done = true;
-            }
-            bool overflow = false;
-            if (valid) {
-                bb.reward[i] = rew;
-                bb.done[i] = done ? 1 : 0;
-#pragma unroll
-                for (int j = 0; j < kDyn; ++j) bb.state[j * ld + i] = y[j];
-                bb.state[kDyn * ld + i] = mass;
-                if (has_ep) {
-                    bb.ep_step[i] = ep_step;
-                    bb.ep_return[i] = ep_ret;
-                }
-                if (bb.flags)
-                    bb.flags[i] = (uint8_t)((status == 1 ? R6_FLAG_GROUND : 0) | (bnd ? R6_FLAG_BOUNDS : 0) | (truncated ? R6_FLAG_TRUNCATED : 0));
-                if (bb.nfev) bb.nfev[i] = (uint8_t)(nfev > 255 ? 255 : nfev);
-                float ob[OD];
-#pragma unroll
-                for (int j = 0; j < kDyn; ++j) {
-                    if (j < OD) ob[j] = y[j] * lds_inv_norm[j];
-                }
-                if (OD == 14) ob[OD - 1] = mass * lds_inv_norm[13];
-#pragma unroll
-                for (int j = 0; j < OD; ++j) bb.obs[i * OD + j] = ob[j];
-                if (done) {
-                    if (bb.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
-                    if (p.auto_reset) {
-                        if (bb.final_obs) {
-#pragma unroll
-                            for (int j = 0; j < OD; ++j) bb.final_obs[i * OD + j] = ob[j];
-                        }
-                        if (bb.fin_return) bb.fin_return[i] = ep_ret;
-                        if (bb.fin_length) bb.fin_length[i] = ep_step;
-                        const int slot = atomicAdd(&rq_count, 1);
-                        if (slot < kResetQueueCap) rq[slot] = (int)i;
-                        else overflow = true;
-                    }
-                }
-            }
-            if (__builtin_expect(__any(overflow), 0)) {
-                __builtin_amdgcn_s_waitcnt(0);
-                if (overflow) reset_env_global<OD>(load_params(), bb, i, seed, step_index, env_offset);
-            }
-        }
-    }
 #ifdef R6_PHASE_TIMING
     const uint64_t pt1 = wall_clock64();
 #endif
