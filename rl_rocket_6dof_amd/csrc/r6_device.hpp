@@ -1119,4 +1119,36 @@ __device__ __forceinline__ void sample_ic_wave(const R6Params& p, uint64_t seed,
     ic[9] *= inv;
 }
 
+// sample_ic_wave() with the reset distribution in LDS (`lo`, `range`: 16 floats each, entries 14 and 15 zero) and the words turned into
+// initial conditions BEFORE they leave their lanes: lane b < 4 converts the four words of Philox block b (14 of the 16 are used) --
+// 16 conversion instructions for the wave instead of 56 on wave-uniform values, and no scalar registers for the 28 distribution
+// parameters (r6_step_k's dynamics wave pays every instruction of a reset on the chain of its tile's K steps: 0.84 us per episode
+// end, round 5).  The same operations on the same operands: bit for bit sample_ic().
+__device__ __forceinline__ void sample_ic_wave_lds(const float* lo, const float* range, uint64_t seed, uint64_t gid, uint64_t step_index, int lane,
+                                                   float (&ic)[R6_STATE_DIM]) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t blk = (uint32_t)lane & 3u;
+    const U4 r = philox4x32_10(U4{(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step_index,
+                                  ((uint32_t)(step_index >> 32) & 0x3FFFFFFFu) | (blk << 30)},
+                               k0, k1);
+    const int j0 = 4 * (int)blk;
+    const float f0 = fmaf((float)(r.x >> 8) * 5.9604644775390625e-08f, range[j0 + 0], lo[j0 + 0]);
+    const float f1 = fmaf((float)(r.y >> 8) * 5.9604644775390625e-08f, range[j0 + 1], lo[j0 + 1]);
+    const float f2 = fmaf((float)(r.z >> 8) * 5.9604644775390625e-08f, range[j0 + 2], lo[j0 + 2]);
+    const float f3 = fmaf((float)(r.w >> 8) * 5.9604644775390625e-08f, range[j0 + 3], lo[j0 + 3]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        ic[4 * b + 0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f0), b));
+        ic[4 * b + 1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f1), b));
+        if (4 * b + 2 < R6_STATE_DIM) ic[4 * b + 2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f2), b));
+        if (4 * b + 3 < R6_STATE_DIM) ic[4 * b + 3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f3), b));
+    }
+    const float n2 = fmaf(ic[6], ic[6], fmaf(ic[7], ic[7], fmaf(ic[8], ic[8], ic[9] * ic[9])));
+    const float inv = 1.0f / sqrtf(n2);
+    ic[6] *= inv;
+    ic[7] *= inv;
+    ic[8] *= inv;
+    ic[9] *= inv;
+}
+
 }  // namespace r6

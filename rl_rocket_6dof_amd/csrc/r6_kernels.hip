@@ -127,6 +127,13 @@ __device__ __forceinline__ R6Buffers load_buffers() {
     return *(const R6Buffers*)(k + sizeof(R6Params));
 }
 
+__device__ __forceinline__ R6StepK load_stepk() {   // kernel argument 2 of the r6_step_k kernels, right behind R6Buffers
+    static_assert(sizeof(R6Buffers) % 8 == 0, "R6StepK must follow R6Buffers without padding");
+    kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const R6StepK*)(k + sizeof(R6Params) + sizeof(R6Buffers));
+}
+
 // env:180-199 for one env, written straight to HBM (used by the dense drain of the reset queue).
 template <int OD>
 __device__ __forceinline__ void reset_env_global(const R6Params& p, const R6Buffers& b, int64_t i, uint64_t seed,
@@ -1427,6 +1434,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : 4)) voi
 #define R6_PAIR_OBS_WAVE 1   // a fourth wave per tile (C) takes every per-step store of the dynamics wave: observation (through an LDS tile, as wide
                              // stores), terminal observation, done / flag bytes.  0 = round 3's three waves (A stores them itself, lane by lane)
 #endif
+#ifndef R6_PAIR_PRIO_A
+#define R6_PAIR_PRIO_A 0   // wave priorities of the roles (s_setprio; A/B switches -- all equal by default: the arbiter serves the oldest wave, A, first)
+#define R6_PAIR_PRIO_B 0
+#define R6_PAIR_PRIO_C 0
+#endif
 constexpr int kPairTiles = 4, kPairNB = R6_PAIR_NB, kPairC = R6_PAIR_OBS_WAVE ? 1 : 0, kPairBlock = 64 * kPairTiles * (1 + kPairNB + kPairC),
               kRing = R6_PAIR_RING, kSlotWords = 21;
 static_assert(kRing >= 2 * kPairNB, "the ring holds at least two steps per reward wave");
@@ -1463,6 +1475,7 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     __shared__ __attribute__((aligned(16))) float ctile[kPairC ? kPairTiles : 1][kPairC ? 64 * OD : 4];
     __shared__ int produced2[kPairTiles], consumed_c[kPairTiles];
     __shared__ float lds_inv_norm[R6_STATE_DIM];
+    __shared__ float lds_ic[2][16];     // Rocket6DOF.reset's distribution: low end, width (sample_ic_wave_lds)
     __shared__ stat_t blk_stats[R6_NUM_STATS];
 
     const int tid = threadIdx.x;
@@ -1489,6 +1502,10 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
 #endif
     if (tid < R6_NUM_STATS) blk_stats[tid] = 0ull;
     if (tid < R6_STATE_DIM) lds_inv_norm[tid] = p.inv_norm[tid];
+    if (tid < 16) {
+        lds_ic[0][tid] = tid < R6_STATE_DIM ? p.ic_lo[tid < R6_STATE_DIM ? tid : 0] : 0.0f;
+        lds_ic[1][tid] = tid < R6_STATE_DIM ? p.ic_range[tid < R6_STATE_DIM ? tid : 0] : 0.0f;
+    }
     if (tid < kPairTiles) {
         produced[tid] = 0;
         returned[tid] = 0;
@@ -1501,6 +1518,11 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
     const uint64_t step_base = b.step_base ? *b.step_base : (uint64_t)0;
     __syncthreads();
 
+    if (R6_PAIR_PRIO_A | R6_PAIR_PRIO_B | R6_PAIR_PRIO_C) {
+        if (role_c) __builtin_amdgcn_s_setprio(R6_PAIR_PRIO_C);
+        else if (role_b) __builtin_amdgcn_s_setprio(R6_PAIR_PRIO_B);
+        else __builtin_amdgcn_s_setprio(R6_PAIR_PRIO_A);
+    }
     int seq = 0;   // steps this pair has gone through (its tiles one after the other): what the ring's counters count
     bool ok = true;   // false: the partner never arrived (abort): leave the loops, still meet the workgroup at its last barrier
 #pragma unroll 1
@@ -1512,6 +1534,13 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
         const int lane_ld = live ? lane : 0;
         if (!role_b && !role_c) {
             // ================================= wave A: what the next step needs ==========================================
+            // Each role re-reads the kernel arguments IT uses from the kernarg segment, inside its own branch (round 5): taken from
+            // the function's parameters they are live through all three branches of the tile loop -- the scalar-register pressure
+            // of the kernel is then the UNION of what the roles need, and the overflow came back as v_readlane / v_writelane
+            // (vector instructions: 118 of the ~990 a tile's four waves issue per env step).
+            const R6Params p = load_params();
+            const R6Buffers b = load_buffers();
+            const R6StepK sk = load_stepk();
             float y[kDyn], mass = 4.0e4f, m0 = 4.0e4f, v0 = 0.0f;
             uint32_t ep_step = 0u;
 #pragma unroll
@@ -1601,13 +1630,15 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
 #ifdef R6_TRACE_K
                             ++pk_ends;
 #endif
-                            const R6Params pp = load_params();
                             float(*rs)[64] = rs_obs[slot_of][seq % kRing];
+#ifdef R6_PAIR_PRIO_RESET
+                            __builtin_amdgcn_s_setprio(R6_PAIR_PRIO_RESET);   // the draw is the longest thing on the chain of the tile's K steps
+#endif
                             do {
                                 const int j = __builtin_ctzll(fin);
                                 fin &= fin - 1ull;
                                 float ic[R6_STATE_DIM];
-                                sample_ic_wave(pp, seed, env_offset + (uint64_t)(e0 + j), step_index + (uint64_t)k + step_base, lane, ic);
+                                sample_ic_wave_lds(lds_ic[0], lds_ic[1], seed, env_offset + (uint64_t)(e0 + j), step_index + (uint64_t)k + step_base, lane, ic);
                                 if (lane == j) {
 #pragma unroll
                                     for (int q = 0; q < kDyn; ++q) y[q] = ic[q];
@@ -1618,6 +1649,9 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                                     for (int q = 0; q < OD; ++q) rs[q][lane] = ic[q] * lds_inv_norm[q];
                                 }
                             } while (fin != 0ull);
+#ifdef R6_PAIR_PRIO_RESET
+                            __builtin_amdgcn_s_setprio(R6_PAIR_PRIO_A);
+#endif
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             if (lane == 0) __atomic_store_n((lds_word_t)&produced2[slot_of], seq + 1, __ATOMIC_RELAXED);
                         }
@@ -1697,8 +1731,14 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
             // done / flag bytes, terminal observation, observation (the fresh episode's first one for a lane wave A has reset) -- from
             // the state wave A published, through this wave's own LDS tile as contiguous 16-byte stores.  Nothing waits for C but the
             // slot's next use: the stores (round 3: lane by lane from wave A, 0.9 of a step's 2.4 us) are off the chain of the K steps.
+            const R6Params p = load_params();
+            const R6Buffers b = load_buffers();
+            const R6StepK sk = load_stepk();
             float* const tile = ctile[slot_of];
             const bool full = rem >= 64;
+#ifdef R6_TRACE_K
+            pk1 = wall_clock64();
+#endif
 #pragma unroll 1
             for (int k = 0; k < K; ++k, ++seq) {
                 const bool emit = !last_only || k + 1 == K;
@@ -1763,11 +1803,24 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                 }
                 wave_lds_sync();
             }
+#ifdef R6_TRACE_K
+            pk2 = wall_clock64();
+#endif
         } else {
             // ================================= wave B: reward, records =====================================================
+            const R6Params p = load_params();
+            const R6Buffers b = load_buffers();
+            const R6StepK sk = load_stepk();
 #ifdef R6_TRACE_K
             pk1 = wall_clock64();
 #endif
+            // The episode return the tile comes in with: requested and ARRIVED in front of the K loop (round 5).  Read inside the
+            // loop (`if (k == 0)`) it left one s_waitcnt vmcnt(0) on the merged path of every step -- and gfx9 counts loads and
+            // stores in ONE in-order counter: every step then waited for the acknowledgement of its own reward store (and the terms
+            // stores), ~0.5 us of a reward wave's 2.0 us per step.
+            float ep_ret_in = 0.0f;
+            if (live && has_ep) ep_ret_in = uniform_ptr(b.ep_return + e0)[lane];
+            asm volatile("" : "+v"(ep_ret_in));
 #pragma unroll 1
             for (int k = 0; k < K; ++k, ++seq) {
                 if (seq % kPairNB != par) continue;   // another reward wave's step
@@ -1819,12 +1872,7 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                     break;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                float ep_ret = 0.0f;
-                if (k == 0) {
-                    if (live && has_ep) ep_ret = uniform_ptr(b.ep_return + e0)[lane];
-                } else {
-                    ep_ret = ep_run[slot_of][lane];
-                }
+                float ep_ret = (k == 0) ? ep_ret_in : ep_run[slot_of][lane];
                 ep_ret += rew;
                 if (live && done) {
                     if (b.stats) stats_add_episode(blk_stats, ep_ret, ep_step, ground, bnd, truncated, landed);
@@ -1859,7 +1907,7 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
         o[3] = (double)(uint32_t)wall_clock64();
         o[4] = (double)pk_ends;
         o[5] = (double)pk_wait;
-        o[6] = role_b ? 1.0 : 0.0;
+        o[6] = role_c ? 2.0 : (role_b ? 1.0 : 0.0);
     }
     return;
 #endif
@@ -2096,7 +2144,8 @@ void launch_step_inst(const R6Params& p, const R6Buffers& b, uint64_t seed, uint
         // 2^22 envs 156.7 | 157.2 | 165.1 | 162.9 | 176.7; 6.3 M 228.5 | 230.1 | 229.0 | 233.6 | 236.1; 2^23 298.3 | 297.8 | 292.2 |
         // 303.8 | 309.6 (three sessions: -3.8, -9.4, -6.1 us for four); 12.6 M 472.8 | 473.6 | 474.2 | 485.9 | 493.6)
         int tpw = tune().balanced_tpw.load(std::memory_order_relaxed);
-        if (tpw < 1) tpw = b.n >= R6_NT_MIN_ENVS ? 4 : 2;
+        // (adaptive instances: four at every size -- a wave's stragglers ride in its later tiles: 4 M envs 433.4 -> 397.9 us, round 5)
+        if (tpw < 1) tpw = (INTEG == R6_RK45 || b.n >= R6_NT_MIN_ENVS) ? 4 : 2;
         const int64_t big = n_tiles / (tpw * r6::kWaves);
         balanced = pinned_blocks <= 0 && n_tiles >= 49152 && big > cap;
         blocks = balanced ? (big < R6_MAX_BLOCKS ? big : R6_MAX_BLOCKS) : cap;

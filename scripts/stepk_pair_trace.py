@@ -22,10 +22,10 @@ for K in a.k:
         env.stats.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); env.step_k(acts[:K], out=out); e1.record(); torch.cuda.synchronize()
-        st = env.stats.cpu().numpy()[: (n // 64 // 4) * 12]
+        st = env.stats.cpu().numpy()[: (n // 64 // 4) * 16]
         st = st[(st[:, 0] != 0) | (st[:, 3] != 0)]
         base = st[:, 0].min(); us = lambda x: (x - base) / 100.0
-        for role, name in ((0, "A dynamics"), (1, "B reward  ")):
+        for role, name in ((0, "A dynamics"), (1, "B reward  "), (2, "C outputs ")):
             m = st[:, 6] == role
             t0, t1, t2, t3 = us(st[m, 0]), us(st[m, 1]), us(st[m, 2]), us(st[m, 3])
             print(f"K={K:3d} rep {rep} {name}: launch {e0.elapsed_time(e1) * 1e3:6.1f} us | entry {t0.min():.2f}..{t0.max():.2f} | loop start {t1.mean():.2f} (max {t1.max():.2f}) | "
