@@ -58,6 +58,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef R6_RESET_QUEUE
 #define R6_RESET_QUEUE 2048
 #endif
+#ifndef R6_RESET_QUAD
+#define R6_RESET_QUAD 1         // A/B switch: the dense drain re-samples one env per quad of lanes (1) or one per lane (0)
+#endif
 #define R6_K_DIRECT_OBS_INTERNAL 0x4000     // R6StepK.flags bit set by the launcher (not part of the ABI): obs stored from registers
 #ifndef R6_K_DIRECT_MAX_TILES
 #define R6_K_DIRECT_MAX_TILES 1024          // r6_step_k: up to one 64-env tile per SIMD the direct form is used (65 536 envs: 3.47 -> 3.25 us per step at K = 16; at 262 144 envs it is 35 % slower than the transposing form)
@@ -152,6 +155,65 @@ __device__ __forceinline__ void reset_env_global(const R6Params& p, const R6Buff
     }
     if (b.ep_step) b.ep_step[i] = 0u;
     if (b.ep_return) b.ep_return[i] = 0.0f;
+}
+
+// The same for one env per QUAD of lanes (round 5): lane b = lane & 3 of a quad runs Philox block b and turns its four words into the
+// components 4b .. 4b + 3 of the initial condition, stores them, and the few values that need components of another lane (the
+// quaternion's norm, the speed v0) are fetched within the quad.  A wave re-samples 16 envs in one pass of ~150 instructions; one env
+// per LANE is four Philox blocks in a row, ~450 instructions of a single, latency-bound wave (the drain sits on the critical path of
+// every workgroup, after the barrier).  The same operations on the same operands as sample_ic(): bit for bit the same state.
+// `inv_norm`: the observation normaliser reciprocals in LDS (per-lane index).
+template <int OD>
+__device__ __forceinline__ void reset_env_quad(const R6Buffers& b, const float* inv_norm, int64_t i, bool valid, int lane, uint64_t seed,
+                                               uint64_t step_index, uint64_t env_offset) {
+    const uint64_t step = step_index + (b.step_base ? *b.step_base : (uint64_t)0);
+    const uint64_t gid = env_offset + (uint64_t)i;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t blk = (uint32_t)lane & 3u;
+    const U4 r = philox4x32_10(U4{(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)step, ((uint32_t)(step >> 32) & 0x3FFFFFFFu) | (blk << 30)}, k0, k1);
+    // the distribution, per lane, from the kernarg segment (R6Params is kernel argument 0)
+    const kernarg_ptr_t ka = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto* lo = (const __attribute__((address_space(4))) float*)(ka + offsetof(R6Params, ic_lo));
+    const auto* rg = (const __attribute__((address_space(4))) float*)(ka + offsetof(R6Params, ic_range));
+    const int j0 = 4 * (int)blk;
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = (j0 + k < R6_STATE_DIM) ? j0 + k : 0;
+        f[k] = fmaf((float)(w[k] >> 8) * 5.9604644775390625e-08f, rg[j], lo[j]);
+    }
+    const int q = lane & ~3;
+    // quaternion (components 6, 7 in lane 1 of the quad, 8, 9 in lane 2): normalised with sample_ic()'s expression
+    const float q6 = __shfl(f[2], q + 1), q7 = __shfl(f[3], q + 1), q8 = __shfl(f[0], q + 2), q9 = __shfl(f[1], q + 2);
+    const float n2 = fmaf(q6, q6, fmaf(q7, q7, fmaf(q8, q8, q9 * q9)));
+    const float inv = 1.0f / sqrtf(n2);
+    if (blk == 1u) {
+        f[2] *= inv;
+        f[3] *= inv;
+    } else if (blk == 2u) {
+        f[0] *= inv;
+        f[1] *= inv;
+    }
+    // speed of the initial condition (components 3 | 4, 5)
+    const float c3 = __shfl(f[3], q), c4 = __shfl(f[0], q + 1), c5 = __shfl(f[1], q + 1);
+    const float v0 = sqrtf(fmaf(c3, c3, fmaf(c4, c4, c5 * c5)));
+    if (!valid) return;
+    const int64_t ld = b.ld;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = j0 + k;
+        if (j < R6_STATE_DIM) {
+            b.state[j * ld + i] = f[k];
+            if (b.obs && j < OD) b.obs[i * OD + j] = f[k] * inv_norm[j];
+        }
+    }
+    if (blk == 3u) b.epconst[i] = f[1];          // m0 = the initial mass (component 13)
+    if (blk == 0u) {
+        b.epconst[ld + i] = v0;
+        if (b.ep_step) b.ep_step[i] = 0u;
+        if (b.ep_return) b.ep_return[i] = 0.0f;
+    }
 }
 
 // Episode statistics of a workgroup: exact integer / fixed-point sums in LDS (native 64-bit integer atomics), so that the
@@ -1033,10 +1095,18 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
 #endif
 
         // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
-        const R6Params pp = load_params();
         const int n_rec = n_queued < kResetQueueCap ? n_queued : kResetQueueCap;   // the rest was handled in the loop
+#if R6_RESET_QUAD
+        for (int base = wave * 16; base < n_rec; base += kWaves * 16) {   // 16 envs per wave and pass
+            const int e = base + (lane >> 2);
+            const bool valid = e < n_rec;
+            reset_env_quad<OD>(bb, lds_inv_norm, (int64_t)rq[valid ? e : base], valid, lane, seed, step_index, env_offset);
+        }
+#else
+        const R6Params pp = load_params();
         for (int k = tid; k < n_rec; k += kBlock)
             reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
+#endif
     } else if (!p.auto_reset) {
         const R6Buffers bb = load_buffers();
 #if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE) && !defined(R6_CLOCK_PROBE)
@@ -1434,6 +1504,12 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : 4)) voi
 #define R6_PAIR_OBS_WAVE 1   // a fourth wave per tile (C) takes every per-step store of the dynamics wave: observation (through an LDS tile, as wide
                              // stores), terminal observation, done / flag bytes.  0 = round 3's three waves (A stores them itself, lane by lane)
 #endif
+#ifndef R6_PAIR_A_LAST
+#define R6_PAIR_A_LAST 0   // A/B switch (round 5): 1 = the dynamics wave computes the reward of its tile's LAST step itself -- it has nothing left to do then and
+                           // the reward waves are a step or two behind.  Bit-identical (tests/test_gpu_step_k.py passes with it), and no gain: K = 4 / 16 / 64
+                           // 3.91 / 2.27 / 1.61 -> 4.02 / 2.29 / 1.58 us per env step -- the reward inlined into the dynamics wave's K loop costs that wave
+                           // 20 more spilled scalar registers on every step
+#endif
 #ifndef R6_PAIR_PRIO_A
 #define R6_PAIR_PRIO_A 0   // wave priorities of the roles (s_setprio; A/B switches -- all equal by default: the arbiter serves the oldest wave, A, first)
 #define R6_PAIR_PRIO_B 0
@@ -1557,6 +1633,10 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                 v0 = uniform_ptr(b.epconst + (ld + e0))[lane];
                 if (has_ep) ep_step = uniform_ptr(b.ep_step + e0)[lane];
             }
+#if R6_PAIR_A_LAST
+            float ep_ret_in = 0.0f;      // needed only when the tile's last step is also its first (K == 1)
+            if (live && has_ep && K == 1) ep_ret_in = uniform_ptr(b.ep_return + e0)[lane];
+#endif
             float a0, a1, a2;
             {
                 const gptr<const float> act = uniform_ptr(b.action + e0 * R6_ACTION_DIM);
@@ -1619,6 +1699,44 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __atomic_store_n((lds_word_t)&produced[slot_of], seq + 1, __ATOMIC_RELAXED);
+
+#if R6_PAIR_A_LAST
+                if (k + 1 == K) {
+                    // ---- the LAST step's reward and records: wave B's sequence, operation for operation, on the registers of this wave ----
+                    const R6Params pr = load_params();
+                    RewardOut rw = reward<SHAPING>(pr, y, mass, c, v0);
+                    const bool landed = rw.landed;
+                    float rew = finalize_reward(pr, rw, bnd, fmaf(2.0f * c.thrust, frcp(pr.max_thrust), -1.0f), y);
+                    if (live && b.terms) {
+                        float* trow = b.terms + ((int64_t)k * sk.terms_stride + i);
+#pragma unroll
+                        for (int q = 0; q < R6_NUM_TERMS; ++q) {
+                            *trow = rw.terms[q];
+                            trow += ld;
+                        }
+                    }
+                    if (pr.clip_reward) rew = fminf(fmaxf(rew, pr.clip_lo), pr.clip_hi);
+                    if (live) uniform_ptr(b.reward + ((int64_t)k * sk.reward_stride + e0))[lane] = rew;
+                    if (!PKWAIT(pair_wait((lds_word_t)&returned[slot_of], seq, (lds_word_t)&abort_word))) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    float ep_ret = (k == 0) ? ep_ret_in : ep_run[slot_of][lane];
+                    ep_ret += rew;
+                    if (live && done) {
+                        if (b.stats) stats_add_episode(blk_stats, ep_ret, ep_step, status == 1, bnd, truncated, landed);
+                        if (pr.auto_reset) {
+                            if (b.fin_return) b.fin_return[(int64_t)k * sk.fin_stride + i] = ep_ret;
+                            if (b.fin_length) b.fin_length[(int64_t)k * sk.fin_stride + i] = ep_step;
+                            ep_ret = 0.0f;
+                        }
+                    }
+                    if (live && has_ep) uniform_ptr(b.ep_return + e0)[lane] = ep_ret;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __atomic_store_n((lds_word_t)&returned[slot_of], seq + 1, __ATOMIC_RELAXED);
+                }
+#endif
 
                 if constexpr (kPairC != 0) {
                     // ---- wave C stores this step's outputs; A only starts the next episodes (Rocket6DOF.reset) and hands C their first
@@ -1824,6 +1942,12 @@ __global__ __launch_bounds__(kPairBlock, 1) void step_k_pair_kernel(const R6Para
 #pragma unroll 1
             for (int k = 0; k < K; ++k, ++seq) {
                 if (seq % kPairNB != par) continue;   // another reward wave's step
+#if R6_PAIR_A_LAST
+                if (k + 1 == K) {   // the dynamics wave's (see there): nothing to read, the slot is free as far as this wave is concerned
+                    if (lane == 0) __atomic_store_n((lds_word_t)&consumed[slot_of][par], seq / kPairNB + 1, __ATOMIC_RELAXED);
+                    continue;
+                }
+#endif
                 const bool emit = !last_only || k + 1 == K;
                 if (!PKWAIT(pair_wait((lds_word_t)&produced[slot_of], seq + 1, (lds_word_t)&abort_word))) {
                     ok = false;
