@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_RAW = 189
 BYTES_WRAPPED = 201            # obs 13 floats (-4 B), ep_step r+w (+8), ep_return r+w (+8)
-TRAFFIC_PROFILE = os.path.join("profiles", "r4_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r5_pmc_traffic.json")
 
 
 def bytes_per_env_step(variant: str, k: int = 1, obs_dim: int = 14) -> float:
@@ -262,7 +262,7 @@ def traffic_from_profile(variant: str, integrator: str, n: int, k: int):
         return None, None
 
 
-VALU_PROFILE = os.path.join("profiles", "r4_pmc_valu.json")
+VALU_PROFILE = os.path.join("profiles", "r5_pmc_valu.json")
 SIMDS = 1024                               # 256 CUs x 4 SIMDs
 # Measured issue cost of a wave64 vector instruction per SIMD once two or more waves are ready (scripts/valu_operand_bench.hip,
 # profiles/r3_experiments.json): vector / constant sources 1.2 ns, a scalar-register (SGPR / vcc) source 1.8 ns, a transcendental
@@ -307,12 +307,12 @@ def valu_from_profile(variant: str, integrator: str, n: int, k: int, kernel_ms: 
         return None
 
 
-STEPK_PROFILE = os.path.join("profiles", "r4_pmc_stepk.json")
+STEPK_PROFILE = os.path.join("profiles", "r5_pmc_stepk.json")
 
 
 def small_batch_bound(n: int, integrator: str, dt, k: int, launch_s: float) -> dict:
     """BASELINE configs[1] (65 536 envs = 1024 tiles on 1024 SIMDs): a launch is bounded by the DEPENDENT chain of one tile's K
-    steps on its SIMD (r6::step_k_pair_kernel: a dynamics wave and two reward waves per tile), not by HBM and not by VALU issue:
+    steps on its SIMD (r6::step_k_pair_kernel: a dynamics wave, two reward waves and an output wave per tile), not by HBM and not by VALU issue:
     the committed PMC pass of this workload (scripts/pmc_stepk.sh) has the waves waiting (s_waitcnt / sleep: a partner's result, a
     load) for about half of their cycles.  Reported: the share of the launch one SIMD needs to issue the tile's vector instructions
     at the measured rates (see valu_issue_time_us) and the profile's split of the wave cycles."""

@@ -32,12 +32,13 @@ if os.path.isdir(pmc):
         if g not in newest or os.path.getmtime(f) > os.path.getmtime(newest[g]):
             newest[g] = f
     for f in (newest[g] for g in sorted(newest)):
-        by = collections.defaultdict(list)
+        by = collections.defaultdict(dict)     # counter -> dispatch -> value (rows of one dispatch, e.g. one per XCD, are summed)
         for r in csv.DictReader(open(f)):
             if "step_kernel" in r["Kernel_Name"]:
-                by[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in by.items():
-            v = v[-30:]
+                d = by[r["Counter_Name"]]
+                d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+        for k, d in by.items():
+            v = [d[i] for i in sorted(d)][-30:]
             res[k] = sum(v) / len(v)
     tiles = (1 << 20) / 64
     cyc = res.get("GRBM_GUI_ACTIVE", 0) / 8
@@ -79,10 +80,17 @@ if os.path.exists(stepk):
         d["share_of_wave_cycles"] = {"valu_issue": raw.get("SQ_ACTIVE_INST_VALU", 0) / wc, "scalar_issue": raw.get("SQ_ACTIVE_INST_SCA", 0) / wc,
                                      "lds_issue": raw.get("SQ_ACTIVE_INST_LDS", 0) / wc, "waiting_s_waitcnt_or_sleep": raw.get("SQ_WAIT_ANY", 0) / wc,
                                      "issue_stall": raw.get("SQ_WAIT_INST_ANY", 0) / wc}
-    json.dump({"kernel": "r6::step_k_pair_kernel<0,0,14> (Euler, acceleration shaping, 14-wide obs): three waves per 64-env tile -- one for the dynamics / reset / "
-                         "observation, two for the reward of alternate steps -- on one SIMD",
+    json.dump({"kernel": "r6::step_k_pair_kernel<0,0,14> (Euler, acceleration shaping, 14-wide obs): four waves per 64-env tile -- one for the dynamics / reset, "
+                         "two for the reward of alternate steps, one for the per-step stores -- on one SIMD",
                "workload": "BASELINE configs[1]: 65 536 envs, Euler dt 0.04, r6_step_k with K = 16 steps per launch, all per-step outputs stored (scripts/stepk_driver.py)",
                "method": "scripts/pmc_stepk.sh: rocprofv3 --kernel-trace --pmc <group>, one counter group per run, mean over the last 30 launches",
                "commit": summ.get("commit"), "driver_line": line, "raw_per_launch": raw, "derived": d},
               open(os.path.join(dst, f"{tag}_pmc_stepk.json"), "w"), indent=1)
+rk45 = os.path.join(ROOT, "gpurun_out", f"pmc_rk45_{tag}", "summary.json")
+if os.path.exists(rk45):
+    raw = json.load(open(rk45))
+    json.dump({"kernel": "r6::step_kernel<2,0,14,false,false> (in-kernel adaptive RK45, scipy's step control), 2^20 envs, steady state of the bench workload",
+               "method": "scripts/pmc_rk45.sh: rocprofv3 --kernel-trace --pmc <group>, one counter group per run of scripts/rk45_driver.py, mean over the last 30 launches; "
+                         "defer_0 = every wave follows its slowest lane (r6_tune rk45_defer 0), defer_6 = the default: a wave's last <= 6 unfinished lanes become guests",
+               "commit": summ.get("commit"), **raw}, open(os.path.join(dst, f"{tag}_pmc_rk45.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_traffic.json")).read())

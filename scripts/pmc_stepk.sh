@@ -21,10 +21,12 @@ res = collections.OrderedDict()
 dur = []
 for f in sorted(glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True)):
     rows = [r for r in csv.DictReader(open(f)) if "step_k_" in r["Kernel_Name"]]
-    by = collections.defaultdict(list)
-    for r in rows: by[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in by.items():
-        v = v[-30:]
+    by = collections.defaultdict(dict)     # counter -> dispatch -> value (rows of one dispatch are summed)
+    for r in rows:
+        d = by[r["Counter_Name"]]
+        d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    for k, d in by.items():
+        v = [d[i] for i in sorted(d)][-30:]
         res[k] = sum(v) / len(v)
 for f in sorted(glob.glob("$OUT/g1/**/*kernel_trace.csv", recursive=True)):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if "step_k_" in r["Kernel_Name"]][-30:]
