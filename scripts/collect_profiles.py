@@ -24,22 +24,8 @@ traffic["method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in 
                      "counters sit on the fabric side of L2 and include Infinity-Cache hits.")
 traffic["ratio_to_algorithmic"] = traffic["hbm_bytes_per_launch"] / traffic["algorithmic_bytes_per_launch"]
 json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-if os.path.isdir(pmc):
-    res = collections.OrderedDict()
-    newest = {}      # gpurun_out/ keeps the files of earlier passes next to the latest: one (the newest) per counter group
-    for f in glob.glob(os.path.join(pmc, "g*", "**", "*counter_collection.csv"), recursive=True):
-        g = os.path.relpath(f, pmc).split(os.sep)[0]
-        if g not in newest or os.path.getmtime(f) > os.path.getmtime(newest[g]):
-            newest[g] = f
-    for f in (newest[g] for g in sorted(newest)):
-        by = collections.defaultdict(dict)     # counter -> dispatch -> value (rows of one dispatch, e.g. one per XCD, are summed)
-        for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"]:
-                d = by[r["Counter_Name"]]
-                d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
-        for k, d in by.items():
-            v = [d[i] for i in sorted(d)][-30:]
-            res[k] = sum(v) / len(v)
+if os.path.exists(os.path.join(pmc, "summary.json")):
+    res = collections.OrderedDict(json.load(open(os.path.join(pmc, "summary.json"))))     # scripts/pmc.sh: mean per launch of every counter
     tiles = (1 << 20) / 64
     cyc = res.get("GRBM_GUI_ACTIVE", 0) / 8
     out = {"command": "scripts/pmc.sh (rocprofv3 --kernel-trace --pmc <group>, one counter group per run, python3 bench.py --steps 30 "

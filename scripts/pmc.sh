@@ -26,4 +26,8 @@ for f in sorted(glob.glob("$OUT/g*/**/*counter_collection.csv", recursive=True))
         v = [d[i] for i in sorted(d)][-30:]
         res[k] = sum(v) / len(v)
 for k, v in res.items(): print(f"{k:28s} {v:16.1f}")
+import json
+json.dump(res, open("$OUT/summary.json", "w"), indent=1)
 PY
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete

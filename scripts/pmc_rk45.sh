@@ -40,3 +40,5 @@ json.dump(out, open("$OUT/summary.json", "w"), indent=1)
 for D, r in out.items():
     print(D, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items()})
 PY
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete

