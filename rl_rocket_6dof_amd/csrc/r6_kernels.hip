@@ -1096,17 +1096,20 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
 
         // ---- dense drain: Rocket6DOF.reset (env:180-199) for every episode this workgroup finished ---
         const int n_rec = n_queued < kResetQueueCap ? n_queued : kResetQueueCap;   // the rest was handled in the loop
-#if R6_RESET_QUAD
-        for (int base = wave * 16; base < n_rec; base += kWaves * 16) {   // 16 envs per wave and pass
-            const int e = base + (lane >> 2);
-            const bool valid = e < n_rec;
-            reset_env_quad<OD>(bb, lds_inv_norm, (int64_t)rq[valid ? e : base], valid, lane, seed, step_index, env_offset);
+        // One env per quad of lanes for the Euler instances (measured on one set of buffers, two sessions: 34.97 -> 34.27 and 34.89 ->
+        // 34.16 us); the RK4 instances keep one env per lane: no gain there (37.25 | 37.31 us), and the quad form moved nine more
+        // scalar-register reloads into their tile loop (the drain shares the kernel's register allocation).
+        if constexpr ((R6_RESET_QUAD != 0) && INTEG == R6_EULER) {
+            for (int base = wave * 16; base < n_rec; base += kWaves * 16) {   // 16 envs per wave and pass
+                const int e = base + (lane >> 2);
+                const bool valid = e < n_rec;
+                reset_env_quad<OD>(bb, lds_inv_norm, (int64_t)rq[valid ? e : base], valid, lane, seed, step_index, env_offset);
+            }
+        } else {
+            const R6Params pp = load_params();
+            for (int k = tid; k < n_rec; k += kBlock)
+                reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
         }
-#else
-        const R6Params pp = load_params();
-        for (int k = tid; k < n_rec; k += kBlock)
-            reset_env_global<OD>(pp, bb, (int64_t)rq[k], seed, step_index, env_offset);
-#endif
     } else if (!p.auto_reset) {
         const R6Buffers bb = load_buffers();
 #if !defined(R6_PHASE_TIMING) && !defined(R6_TRACE) && !defined(R6_CLOCK_PROBE)
