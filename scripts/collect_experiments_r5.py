@@ -90,6 +90,8 @@ E["step_k (review round 4, Next 2b)"] = {
                                                                                   "+ every role re-reads its kernel arguments": {"K=4": 4.11, "K=16": 2.38, "K=64": 1.66}, "+ reset draw from LDS, converted in its lanes": {"K=4": 3.91, "K=16": 2.27, "K=64": 1.61},
                                                                                   "+ the dynamics wave takes the last step's reward (-DR6_PAIR_A_LAST=1, not kept)": {"K=4": 4.02, "K=16": 2.29, "K=64": 1.58}}}
 E["reset_drain_one_env_per_quad (commit af3c13a; build_variant.sh noquad -DR6_RESET_QUAD=0)"] = {"rk4_raw": pooled("r5_swap_quad_rk4.log"), "euler": pooled("r5_swap_quad_euler.log"), "fused_stack": pooled("r5_swap_quad_wrapped.log")}
+E["this_round_against_round_4_on_one_set_of_buffers (build: round 4's sources at 576a206 compiled with the same flags -> variants/libr6dof_r4.so; library af3c13a+: quad reset drain still in the RK4 instances)"] = {
+    "rk4_raw": pooled("r5_swap_r4_vs_r5_rk4.log"), "euler": pooled("r5_swap_r4_vs_r5_euler.log"), "fused_stack": pooled("r5_swap_r4_vs_r5_wrapped.log"), "rk45": pooled("r5_swap_r4_vs_r5_rk45.log")}
 E["grid_barrier_vs_kernel_boundary (review round 4, Next 6)"] = {"commit": "af3c13a", "script": "scripts/grid_barrier_bench.hip", "result": rd("r5_grid_barrier_bench.log").strip()}
 E["ppo_all_reduce_in_the_epoch_graph (review round 4, Next 5)"] = js("ppo_rccl_graph.json")
 json.dump(E, open(os.path.join(ROOT, "profiles", "r5_experiments.json"), "w"), indent=1)
