@@ -15,6 +15,15 @@ OBJ=$C/build/variant_$NAME
 mkdir -p $OUT $OBJ
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-math-errno -fno-slp-vectorize -Wall -Wno-unused-function"
 python3 -m rl_rocket_6dof_amd.build > /dev/null
+# a -D switch that is read outside r6_kernels.hip (r6_device.hpp is compiled into r6_rollout.hip too) with only r6_kernels.hip recompiled
+# would link mixed objects without a word (round-4 advice): such a switch turns --all on by itself
+for a in "$@"; do
+  case "$a" in -D*) m=${a#-D}; m=${m%%=*};
+    if [ $ALL == 0 ] && grep -q "\b$m\b" $C/r6_device.hpp $C/r6_policy_device.hpp $C/r6_rollout.hip $C/r6_policy.hip $C/r6_ppo_update.hip 2>/dev/null; then
+      echo "[build_variant] $m is read outside r6_kernels.hip: recompiling every unit (--all)" >&2; ALL=1
+    fi;;
+  esac
+done
 if [ $ALL == 1 ]; then UNITS="r6_kernels r6_policy r6_ppo_update r6_rollout"; else UNITS="r6_kernels"; fi
 PIDS=""
 for u in $UNITS; do hipcc $FLAGS "$@" -c $C/$u.hip -o $OBJ/$u.o 2> $OBJ/$u.log & PIDS="$PIDS $!"; done
