@@ -994,7 +994,15 @@ __device__ __forceinline__ RewardOut reward(const R6Params& p, const float (&y)[
     o.terms[6] = (rn < p.max_r_f && zero_h) ? fmaxf(p.max_v_f - vn, 0.0f) * p.w_v_f : 0.0f;  // env:401
     o.terms[7] = 0.0f;
     o.landed = landed;
-    o.sum = ((((((o.terms[0] + o.terms[1]) + o.terms[2]) + o.terms[3]) + o.terms[4]) + o.terms[5]) + o.terms[6]);
+    {
+        // The sum of the seven terms, in the reference's order (env:342-361) and with NO contraction: several terms are products
+        // (beta T, w_r_f max(..), ...), and hipcc may fuse such a product into the addition that consumes it in one inlined
+        // copy of this function and not in another -- the copy of step_kernel's tile loop and the copy of its guest flush
+        // disagreed in the last bit of the total with all seven terms equal (round 5).  Without the licence to contract, every
+        // copy rounds every term and every partial sum: the same total wherever this is inlined.
+#pragma clang fp contract(off)
+        o.sum = ((((((o.terms[0] + o.terms[1]) + o.terms[2]) + o.terms[3]) + o.terms[4]) + o.terms[5]) + o.terms[6]);
+    }
     return o;
 }
 
@@ -1020,7 +1028,10 @@ __device__ __forceinline__ float finalize_reward(const R6Params& p, RewardOut& r
         rw.terms[0] = 0.0f;
         rw.terms[1] = tpen;
         rw.terms[2] = 0.0f;
-        r = (((rw.terms[3] + rw.terms[4]) + rw.terms[5]) + rw.terms[6]) + tpen;
+        {
+#pragma clang fp contract(off)
+            r = (((rw.terms[3] + rw.terms[4]) + rw.terms[5]) + rw.terms[6]) + tpen;
+        }
     } else {
         r = rw.sum + (bnd ? p.bounds_penalty : 0.0f);
     }

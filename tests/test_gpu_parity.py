@@ -622,16 +622,18 @@ def test_rk45_adaptive_twin_vs_reference(torch_cuda, cfg, P, fixture):
     assert same > 0.97 and abs(nfev.mean() - G["nfev"].mean()) < 0.2
 
 
-@pytest.mark.parametrize("n,kw", [(150_037, dict()),
-                                  (9_001, dict(remove_mass=True, clip_reward=(-1, 100), max_episode_steps=7, reward_shaping="velocity"))])
-def test_rk45_straggler_pass_is_bit_identical(torch_cuda, cfg, n, kw):
+@pytest.mark.parametrize("n,grid,K,kw", [(150_037, 48, 24, dict()),                       # 12 tiles per wave: hand-over, hosting, list recycling
+                                         (9_001, 8, 24, dict(remove_mass=True, clip_reward=(-1, 100), max_episode_steps=7, reward_shaping="velocity")),
+                                         (1 << 20, 0, 6, dict())])                      # the bench's own launch shape: 4 tiles per wave
+def test_rk45_straggler_pass_is_bit_identical(torch_cuda, cfg, n, grid, K, kw):
     """integrator="rk45": a wave hands its last few unfinished lanes (the 0.8 % of env steps that need a third or fourth RK step,
-    simulator.py:83-88 through scipy's step control) to the workgroup's straggler pass instead of following them
-    (r6_kernels.hip step_kernel, r6_tune("rk45_defer")).  Whoever integrates a lane does the same arithmetic: every output of every
+    simulator.py:83-88 through scipy's step control) over as GUESTS -- they ride in idle lanes of the wave's own later attempts -- instead
+    of following them (r6_kernels.hip step_kernel, r6_tune("rk45_defer")).  Whoever integrates a lane does the same arithmetic: every output of every
     step -- observation, reward, done, flag byte, nfev, the 7 reward terms, terminal observation / return / length, the state, the
     episode counters and statistics -- must equal the run without the hand-over, bit for bit; ragged last tile, in-kernel resets,
-    the fused wrappers and velocity shaping included.  Also: the pass really ran (steps with nfev >= 20 exist), and a threshold of
-    64 lanes with a full stash (everybody defers, the stash overflows, the rest goes on in the wave) changes nothing either."""
+    the fused wrappers and velocity shaping included.  Also: lanes that need a third RK step exist (nfev >= 20), and a threshold of
+    64 lanes (the list is full at once: what does not fit goes on in the wave, the list is recycled after every tile) changes
+    nothing either."""
     torch = torch_cuda
     import json
 
@@ -641,13 +643,15 @@ def test_rk45_straggler_pass_is_bit_identical(torch_cuda, cfg, n, kw):
     if kw.pop("reward_shaping", None) == "velocity":
         c2["reward_shaping_type"] = "velocity"
         c2["landing_params"]["waypoint"] = 50
-    K = 24
+    # (a wave hands lanes over only when it has a LATER tile to host them in: the grid is pinned so that every wave walks several
+    #  tiles -- with the default grid a batch below 524 288 envs is one tile per wave and the hand-over never happens)
     gen = torch.Generator(device="cuda:0").manual_seed(7)
     acts = [(torch.rand((n, 3), generator=gen, device="cuda:0") * 2 - 1) for _ in range(K)]
     G4 = load_golden("g4_ground_events.npz")
     runs = []
     try:
-        for defer in (0, 6, 64):
+        _lib.tune("grid_blocks", grid)
+        for defer in (0, 6, 64) if n < (1 << 20) else (0, 6):
             _lib.tune("rk45_defer", defer)
             env = BatchedRocket6DOF(n, c2, integrator="rk45", seed=3, record_flags=True, record_terms=True, record_nfev=True,
                                     track_episodes=True, **kw)
@@ -667,8 +671,9 @@ def test_rk45_straggler_pass_is_bit_identical(torch_cuda, cfg, n, kw):
             del env
     finally:
         _lib.tune("rk45_defer", 6)
+        _lib.tune("grid_blocks", 0)
     nf = torch.stack([s[4] for s in runs[0][:K]])
-    assert int((nf >= 20).sum()) > K, "no env step needed a third RK step: the straggler pass was not exercised"
+    assert int((nf >= 20).sum()) > K, "no env step needed a third RK step: the hand-over was not exercised"
     assert int(torch.stack([s[2] for s in runs[0][:K]]).sum()) > 200      # episode ends (ground events of the G4 states, bounds, time limit): resets ran
     for other in runs[1:]:
         for k, (a, b) in enumerate(zip(runs[0], other)):
