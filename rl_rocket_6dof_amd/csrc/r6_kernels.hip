@@ -1122,7 +1122,11 @@ __global__ __launch_bounds__(kBlock, (INTEG == R6_RK45 ? R6_RK45_WAVES : (INTEG 
         __builtin_amdgcn_s_waitcnt(0);
         const uint64_t cp_s1 = __builtin_amdgcn_s_memtime();
         const uint64_t cp_r1 = wall_clock64();
+#ifdef R6_CLOCK_RING      // a ring of R6_CLOCK_RING launches (keyed by the step index) instead of one: the host reads it every R6_CLOCK_RING launches
+        double* o = b.stats + ((int64_t)(step_index % R6_CLOCK_RING) * gridDim.x + blockIdx.x) * R6_NUM_STATS;
+#else
         double* o = b.stats + (int64_t)blockIdx.x * R6_NUM_STATS;
+#endif
         o[0] = (double)(cp_s1 - cp_s0);
         o[1] = (double)(cp_r1 - cp_r0);
         o[2] = (double)(uint32_t)cp_r0;

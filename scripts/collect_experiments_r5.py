@@ -63,6 +63,19 @@ if b1 and b2:
         "reading": "slow episodes of 1.5-3 ms at +5 ... +15 % arrive every 8-25 ms; they do not replay with the data, are absent from the constant-work launches of the same kernel "
                    "(no episode ends: 33.8 us, +-0.8 %) and from the memory skeleton (31.1 us, +-0.3 %), and absent when the launches are spaced out (35.9 us, p10 35.3, p90 36.8): the chip's clock management "
                    "under sustained full load (round 4's clock probe: 2.03-2.19 GHz during RK4 launches against 2.38 GHz for the skeleton), not the workload"}
+cv = js("r5_clock_vs_duration.json")
+if cv:
+    import numpy as np
+    us, g = np.array(cv["series_us"][1:]), np.array(cv["series_ghz"][1:])     # the first chunk carries the set-up of the copy path
+    med = float(np.median(us)); slow = us > 1.04 * med
+    E["shader_clock_against_chunk_time (back to back; -DR6_CLOCK_PROBE -DR6_CLOCK_RING=10 build at commit after 96c78ca, scripts/clock_vs_duration.py)"] = {
+        "what": "199 chunks of 20 launches of the bench workload right after a synchronize + allocation; every workgroup of every launch writes its s_memtime cycles over its 100 MHz ticks into a ring the host copies every 10 launches",
+        "corr(chunk time, chunk shader clock)": float(np.corrcoef(us, g)[0, 1]), "chunk_time_us": {"median": med, "p10": float(np.percentile(us, 10)), "p90": float(np.percentile(us, 90))},
+        "clock_ghz": {"median": float(np.median(g)), "min": float(g.min()), "max": float(g.max())},
+        "chunks_above_1.04_x_median": {"n": int(slow.sum()), "clock_ghz": float(g[slow].mean()), "time_us": float(us[slow].mean())}, "the_others": {"clock_ghz": float(g[~slow].mean()), "time_us": float(us[~slow].mean())},
+        "first_60_chunks_us": [round(float(x), 1) for x in us[:60]], "first_60_chunks_ghz": [round(float(x), 2) for x in g[:60]],
+        "reading": "the launch time follows the shader clock (correlation -0.91): 54 us at 1.56 GHz right after the idle gap, 38.5 us at 2.35 GHz, the dips inside the steady state (40.2-40.3 us) at 2.12-2.14 GHz; "
+                   "(with a copy after EVERY launch the launches are spaced out and the dips do not occur: 40.7 us, p10 40.3, p90 41.7 including the copy)"}
 E["packed_fp32 (review round 4, Next 3)"] = {"commit": "9cdac53", "script": "scripts/pk_rate_bench.hip", "ns_per_wave64_instruction_and_simd": [l for l in rd("r5_pk_rate_bench.log").split("\n") if l.startswith("waves/SIMD")],
                                              "reading": "a v_pk_fma_f32 (two float operations per lane) costs 2.15-2.24 ns at four / five waves per SIMD against 1.14-1.22 ns for a plain v_fma_f32 with vector sources: two plain "
                                                         "instructions are 2.3-2.4 ns -- packing saves at most 7 % on the PACKABLE instructions if no register move is added, i.e. < 3 % of an RK45 attempt: dropped by the review's own stop rule, "
