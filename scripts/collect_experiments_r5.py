@@ -48,6 +48,14 @@ E["driver_shape (review round 4, Next 1)"] = {
                                      "timed20_mean_kernel_us": tr["timed20_mean_dur_us"], "burnin_mean_us_by_200_launches": [round(x, 1) for x in tr["burnin_mean_us_by_200"]]},
     "reading": "a 20-launch region pays +0.8 us per step for the first launch after the barrier (HIP events) and +0.9 us more for the host's wake-up (wall clock); after >= 20 ms of idleness the whole "
                "block runs at 39.4-45 us (the chip has clocked down); the first 30 ms of a process run 32.7 -> 53 -> 36 us per launch"}
+def _ds(f):
+    b = js(f)
+    return b and {"file": f, "lib": b["config"]["lib_commit"], "wall_us": round(b["ms_per_step"] * 1e3, 2), "hip_events_us": round(b["roofline"]["kernel_us"], 2), "frac": round(b["roofline"]["frac"], 3),
+                  "steady_median_us": round(b["steady"]["median"], 2), "steady_p90_us": round(b["steady"]["p90"], 2), "timed_region_over_median": round(b["steady"]["timed_region_over_median"], 3)}
+E["driver_shape (review round 4, Next 1)"]["untraced_runs_with_the_round_5_bench (1 s pre-roll, steady record)"] = [x for x in (
+    {"file": "profiles/r5_bench_line_driver_shape_slow_episode.json", "lib": "ce05765", "wall_us": 42.0, "hip_events_us": 41.0, "frac": 0.604, "steady_median_us": 36.97, "steady_p90_us": 39.99, "timed_region_over_median": 1.109},
+    _ds("r5_bench_driver_shape.json"), _ds("r5_bench_driver_shape_final.json")) if x]
+E["driver_shape (review round 4, Next 1)"]["untraced_runs_note"] = "three fresh boxes: two of the three 20-launch samples sat in a clock dip (1.09-1.11 x their own steady median), one did not (0.99)"
 b1, b2 = js("r5_burst_probe.json"), js("r5_burst_probe2.json")
 if b1 and b2:
     import statistics as st
