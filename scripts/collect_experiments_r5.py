@@ -56,6 +56,14 @@ E["driver_shape (review round 4, Next 1)"]["untraced_runs_with_the_round_5_bench
     {"file": "profiles/r5_bench_line_driver_shape_slow_episode.json", "lib": "ce05765", "wall_us": 42.0, "hip_events_us": 41.0, "frac": 0.604, "steady_median_us": 36.97, "steady_p90_us": 39.99, "timed_region_over_median": 1.109},
     _ds("r5_bench_driver_shape.json"), _ds("r5_bench_driver_shape_final.json")) if x]
 E["driver_shape (review round 4, Next 1)"]["untraced_runs_note"] = "three fresh boxes: two of the three 20-launch samples sat in a clock dip (1.09-1.11 x their own steady median), one did not (0.99)"
+tp = js("r5_timed_region_probe.json")
+if tp:
+    E["driver_shape (review round 4, Next 1)"]["a_20_launch_region_behind_a_barrier_against_one_in_a_continuous_stream (scripts/timed_region_probe.py, 40 interleaved repetitions, HIP events, us per launch)"] = {
+        "A: bench.py's sequence ([200 launches, sync] x 3, barrier, 5 warm-up, barrier, barrier, 20 timed)": {k: v for k, v in tp["A"].items() if k != "values"},
+        "B: no synchronize between pre-roll and warm-up, ONE barrier before the 20 timed": {k: v for k, v in tp["B"].items() if k != "values"},
+        "C: the 20 launches inside a continuous stream (no synchronize before them)": {k: v for k, v in tp["C"].items() if k != "values"},
+        "reading": "the barrier the contract puts in front of the timed region costs a 20-launch sample ~1.5 us per launch (4 %) against the same launches in a continuous stream -- 0.8 us of it the first launch's start-up -- "
+                   "and doubles its chance of reading > 1.06 x the continuous median (0.35-0.45 against 0.17); the additional synchronizes of bench.py's sequence change nothing (A = B)"}
 b1, b2 = js("r5_burst_probe.json"), js("r5_burst_probe2.json")
 if b1 and b2:
     import statistics as st
