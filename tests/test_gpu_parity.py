@@ -624,6 +624,7 @@ def test_rk45_adaptive_twin_vs_reference(torch_cuda, cfg, P, fixture):
 
 @pytest.mark.parametrize("n,grid,K,kw", [(150_037, 48, 24, dict()),                       # 12 tiles per wave: hand-over, hosting, list recycling
                                          (9_001, 8, 24, dict(remove_mass=True, clip_reward=(-1, 100), max_episode_steps=7, reward_shaping="velocity")),
+                                         (40_003, 16, 10, dict(timestep=0.5)),          # the reference's simulator-test step: 4-6 RK steps per env step, guests under way for several tiles
                                          (1 << 20, 0, 6, dict())])                      # the bench's own launch shape: 4 tiles per wave
 def test_rk45_straggler_pass_is_bit_identical(torch_cuda, cfg, n, grid, K, kw):
     """integrator="rk45": a wave hands its last few unfinished lanes (the 0.8 % of env steps that need a third or fourth RK step,
