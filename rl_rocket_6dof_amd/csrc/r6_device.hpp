@@ -543,6 +543,20 @@ constexpr Derived make_derived() {
 constexpr Derived T = make_derived();
 // component of the 13-vector behind stage-vector slot d
 __device__ __forceinline__ constexpr int comp(int d) { return d < 7 ? 3 + d : 4 + d; }   // 3,4,5 | 6,7,8,9 | 11,12
+// acc + coef * k for a tableau coefficient: a zero coefficient (B[1], E[1], the first column of P below its first row, ...) is no
+// instruction at all.  The calls sit in fully unrolled loops over constexpr tables, so the test folds at compile time; written as
+// plain fmaf the compiler has to keep `fma(0, k, acc)` (0 * inf is NaN) -- 41 such instructions in the main path of an attempt and 80
+// in its event path (round 5, found in the disassembly).  For finite k the result is the same number (scipy's dot products add the
+// zero terms too); only the sign of an exact zero can differ.
+__device__ __forceinline__ float fma_c(float coef, float k, float acc) { return coef == 0.0f ? acc : fmaf(coef, k, acc); }
+// ... and a sum that starts with a PRODUCT: written `acc = 0; acc = fma(c, k, acc)` the first term is a v_fma_f32 with a zero addend
+// (not a multiply: -0 + 0 is +0) whose coefficient sits in a scalar register (a VOP3 takes no literal on gfx9: 1.8 ns against the 1.2 ns
+// of a v_mul_f32 with a literal) -- 97 of an attempt's 1409 vector instructions.  `first` folds at compile time like the zero test.
+__device__ __forceinline__ void acc_c(float coef, float k, float& acc, bool& first) {
+    if (coef == 0.0f) return;
+    acc = first ? coef * k : fmaf(coef, k, acc);
+    first = false;
+}
 }  // namespace dp45
 
 // What one lane carries from attempt to attempt of the adaptive integrator (next to its state y and the control of the step):
@@ -655,16 +669,18 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
         float ys[kDyn];
         {   // altitude (the only position the forces read): x + h C v_x + h^2 sum_m AA[st][m] Kv_x[m]
             float acc = 0.0f;
+            bool f1 = true;
 #pragma unroll
-            for (int m = 0; m + 1 < st; ++m) acc = fmaf(T.AA[st][m], K[m][0], acc);
+            for (int m = 0; m + 1 < st; ++m) acc_c(T.AA[st][m], K[m][0], acc, f1);
             ys[0] = fmaf(hh, acc, fmaf(h * C[st], y[3], y[0]));
             ys[1] = ys[2] = 0.0f;   // never read
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             float acc = 0.0f;
+            bool f1 = true;
 #pragma unroll
-            for (int j = 0; j < st; ++j) acc = fmaf(A[st][j], K[j][d], acc);
+            for (int j = 0; j < st; ++j) acc_c(A[st][j], K[j][d], acc, f1);
             ys[comp(d)] = fmaf(h, acc, y[comp(d)]);
         }
         ys[10] = y[10];
@@ -673,15 +689,17 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         float acc = 0.0f;
+        bool f1 = true;
 #pragma unroll
-        for (int m = 0; m < 5; ++m) acc = fmaf(T.BA[m], K[m][i], acc);
+        for (int m = 0; m < 5; ++m) acc_c(T.BA[m], K[m][i], acc, f1);
         ynew[i] = fmaf(hh, acc, fmaf(h, y[3 + i], y[i]));
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         float acc = 0.0f;
+        bool f1 = true;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc = fmaf(B[j], K[j][d], acc);
+        for (int j = 0; j < 6; ++j) acc_c(B[j], K[j][d], acc, f1);
         ynew[comp(d)] = fmaf(h, acc, y[comp(d)]);
     }
     ynew[10] = y[10];
@@ -692,8 +710,9 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
 #pragma unroll
     for (int i = 0; i < 3; ++i) {   // position rows: h^2 sum_m EA[m] Kv[m]
         float e = 0.0f;
+        bool f1 = true;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) e = fmaf(T.EA[m], K[m][i], e);
+        for (int m = 0; m < 6; ++m) acc_c(T.EA[m], K[m][i], e, f1);
         const float sc = fmaf(fmaxf(fabsf(y[i]), fabsf(ynew[i])), kRtol, kAtol);
         en += sq(e * hh * frcp(sc));
     }
@@ -701,7 +720,7 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
     for (int d = 0; d < D; ++d) {
         float e = E[6] * Kn[d];
 #pragma unroll
-        for (int j = 5; j >= 0; --j) e = fmaf(E[j], K[j][d], e);
+        for (int j = 5; j >= 0; --j) e = fma_c(E[j], K[j][d], e);
         const float sc = fmaf(fmaxf(fabsf(y[comp(d)]), fabsf(ynew[comp(d)])), kRtol, kAtol);
         en += sq(e * h * frcp(sc));
     }
@@ -727,8 +746,9 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float acc = 0.0f;
+                bool f1 = true;
 #pragma unroll
-                for (int m = 0; m < 6; ++m) acc = fmaf(T.PA[m][k], K[m][i], acc);
+                for (int m = 0; m < 6; ++m) acc_c(T.PA[m][k], K[m][i], acc, f1);
                 qq[k] = fmaf(h, acc, T.PS[k] * y[3 + i]);
             }
         };
@@ -746,13 +766,14 @@ __device__ __forceinline__ void rk45_attempt(float (&y)[kDyn], float mass0, cons
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             float qq[4] = {0, 0, 0, 0};
+            bool fq[4] = {true, true, true, true};
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) qq[k] = fmaf(K[j][d], P[j][k], qq[k]);
+                for (int k = 0; k < 4; ++k) acc_c(P[j][k], K[j][d], qq[k], fq[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) qq[k] = fmaf(Kn[d], P[6][k], qq[k]);
+            for (int k = 0; k < 4; ++k) acc_c(P[6][k], Kn[d], qq[k], fq[k]);
             yev[comp(d)] = fmaf(h * th, fmaf(fmaf(fmaf(qq[3], th, qq[2]), th, qq[1]), th, qq[0]), y[comp(d)]);
         }
 #pragma unroll
