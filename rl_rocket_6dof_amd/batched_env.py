@@ -50,6 +50,14 @@ def _leading_dim(n: int) -> int:
     return ld + 1024 if ld % 2048 == 0 else ld
 
 
+def group_bounds(n: int, groups: int) -> List[int]:
+    """Env group g of ``BatchedRocket6DOF(groups=G)`` = envs [bounds[g], bounds[g + 1]): near-equal contiguous ranges cut at multiples
+    of 64 (tile-aligned SoA rows; 16-byte aligned action / observation blocks whatever the observation width)."""
+    if groups < 1 or (groups > 1 and n < 128 * groups):
+        raise ValueError("groups must be >= 1 and every group needs at least two 64-env tiles")
+    return [min(n, (n * g // groups + 32) // 64 * 64) for g in range(groups)] + [n]
+
+
 class StaleInfosError(RuntimeError):
     pass
 
@@ -158,8 +166,7 @@ class BatchedRocket6DOF(VecEnv):
         if group_sync not in ("caller", "none"):
             raise ValueError("group_sync must be 'caller' or 'none'")
         self.groups, self.group_sync = int(groups), group_sync
-        if self.groups < 1 or (self.groups > 1 and num_envs < 128 * self.groups):
-            raise ValueError("groups must be >= 1 and every group needs at least two 64-env tiles")
+        group_bounds(int(num_envs), self.groups)      # raises on a bad split before anything is allocated
         self.lib = _lib.load(lib_path)   # raises if the HIP extension is missing -- no fallback
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedRocket6DOF needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -210,7 +217,7 @@ class BatchedRocket6DOF(VecEnv):
         # float64: counts stay exact.  One block of MAX_BLOCKS per-workgroup rows per env group: concurrent launches never share a row
         self.stats = torch.zeros((MAX_BLOCKS * self.groups, NUM_STATS), dtype=torch.float64, device=dev) if track else None
         # group g = envs [bounds[g], bounds[g + 1]): cut at multiples of 64 (tile-aligned rows, 16-byte aligned action / obs blocks)
-        self._group_bounds = [min(n, (n * g // self.groups + 32) // 64 * 64) for g in range(self.groups)] + [n]
+        self._group_bounds = group_bounds(n, self.groups)
         self._group_streams = [torch.cuda.Stream(device=dev) for _ in range(self.groups)] if self.groups > 1 else []
         self._fork_event = torch.cuda.Event() if self.groups > 1 else None
         self._join_events = [torch.cuda.Event() for _ in range(self.groups)] if self.groups > 1 else []

@@ -191,3 +191,24 @@ def test_builtin_defaults_equal_reference_config_and_yaml_loader(tmp_path):
     f.write_text(yaml.safe_dump({"env_config": ref, "sb3_config": {"max_time": 150, "total_timesteps": 1e6}}))
     sb3, env = load_config(str(f))
     assert norm(env) == norm(ref) and sb3["max_time"] == 150
+
+
+def test_env_group_bounds_are_tile_aligned_and_cover_the_batch():
+    """BatchedRocket6DOF(groups=G) (round 5): contiguous env groups cut at multiples of 64 -- tile-aligned rows, 16-byte aligned
+    action (12 B per env) and observation (52 / 56 B per env) blocks -- covering [0, n) without gaps; a split that would leave a group
+    with less than two tiles is refused.  (The launches themselves: tests/test_gpu_fullsize.py.)"""
+    from rl_rocket_6dof_amd.batched_env import group_bounds
+
+    for n in (128, 129, 4096, 200_003, 1 << 20, (1 << 20) + 77, 3 * (1 << 19) + 5):
+        for g in (1, 2, 3, 4, 7):
+            if g > 1 and n < 128 * g:
+                with pytest.raises(ValueError):
+                    group_bounds(n, g)
+                continue
+            b = group_bounds(n, g)
+            assert b[0] == 0 and b[-1] == n and len(b) == g + 1
+            assert all(x % 64 == 0 for x in b[:-1]) and all(b[i] < b[i + 1] for i in range(g))
+            assert all((x * 12) % 16 == 0 and (x * 52) % 16 == 0 and (x * 56) % 16 == 0 for x in b[:-1])
+            assert max(b[i + 1] - b[i] for i in range(g)) - min(b[i + 1] - b[i] for i in range(g)) <= 128
+    with pytest.raises(ValueError):
+        group_bounds(1000, 0)
