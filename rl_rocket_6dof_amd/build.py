@@ -118,7 +118,10 @@ def _stamp_commit():
     bench.py reports it)."""
     try:
         root = os.path.join(HERE, "..")
-        rev = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        # the last commit that touched the library's sources (not HEAD: commits of docs, tests or scripts do not make a new library,
+        # and profiles/ are stamped with this string)
+        rev = subprocess.run(["git", "-C", root, "log", "-1", "--format=%h", "--", "rl_rocket_6dof_amd/csrc", "include"], capture_output=True,
+                             text=True, timeout=10).stdout.strip()
         dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "rl_rocket_6dof_amd/csrc", "include"], capture_output=True,
                                text=True, timeout=10).stdout.strip()
         if rev:
