@@ -585,11 +585,12 @@ def ppo_configs4_side_measurement(torch, dev, iters: int = 2, warm: int = 2) -> 
     from rl_rocket_6dof_amd import dist as r6dist
     from rl_rocket_6dof_amd.ppo import PPO, PPOConfig
 
-    n, steps, bs = 1 << 20, 64, 1 << 16
+    n, steps = 1 << 20, 64
     out = {"workload": "PPO, one GPU's share of BASELINE configs[4]: 2^20 wrapped envs (remove-mass obs, reward clip, 1500-step limit) x 64 steps per "
                        "rollout, two separate tanh MLPs (64, 64), 10 epochs x 1024 minibatches of 65 536 samples, one episode-summary gather per "
                        "rollout, random initial weights"}
-    try:
+
+    def run(bs: int) -> dict:
         env = BatchedRocket6DOF(n, default_env_config(), remove_mass=True, clip_reward=(-1, 100), max_episode_steps=1500, seed=1, device=dev)
         algo = PPO(env, PPOConfig(n_steps=steps, batch_size=bs, net_arch=(64, 64), shared_trunk=False, log_std_min=-2.5))
         gathered = []
@@ -612,12 +613,21 @@ def ppo_configs4_side_measurement(torch, dev, iters: int = 2, warm: int = 2) -> 
             upd += t2 - t1
         roll, upd = roll / iters, upd / iters
         mb = 10 * (steps * n // bs)
-        out.update({"env_steps_per_s": steps * n / (roll + upd), "rollout_gae_and_gather_ms": roll * 1e3, "update_ms": upd * 1e3,
-                    "minibatch_steps_per_iteration": mb, "minibatch_step_us": upd / mb * 1e6, "iterations_timed": iters,
-                    "rollout_us_per_env_step_of_the_batch": roll / steps * 1e6, "fused_update": algo.fused_update is not None,
-                    "update_from_graph": algo._graph is not None, "episodes_in_last_gather": float(gathered[-1][:, 0].sum())})
+        rec = {"env_steps_per_s": steps * n / (roll + upd), "rollout_gae_and_gather_ms": roll * 1e3, "update_ms": upd * 1e3,
+               "minibatch_steps_per_iteration": mb, "minibatch_step_us": upd / mb * 1e6, "iterations_timed": iters,
+               "rollout_us_per_env_step_of_the_batch": roll / steps * 1e6, "fused_update": algo.fused_update is not None,
+               "update_from_graph": algo._graph is not None, "episodes_in_last_gather": float(gathered[-1][:, 0].sum())}
         del algo, env, gathered
         torch.cuda.empty_cache()
+        return rec
+
+    try:
+        out.update(run(1 << 16))
+        # the same job with SB3's own ratio of minibatches to rollout (PPO defaults: 2048 samples / 64 = 32 minibatches per epoch; here 64 of
+        # 2^20 samples): the update's fixed cost per minibatch step (weight images, partial sets, reduce, clip + Adam) is paid 16x less often
+        big = run(1 << 20)
+        big["workload"] = "as above with 64 minibatches of 1 048 576 samples per epoch"
+        out["minibatch_2^20"] = big
     except Exception as e:   # noqa: BLE001 -- a side figure must not cost the line
         out["error"] = f"{type(e).__name__}: {e}"[:300]
     return out
