@@ -123,5 +123,18 @@ E["this_round_against_round_4_on_one_set_of_buffers (build: round 4's sources at
     "rk4_raw": pooled("r5_swap_r4_vs_r5_rk4.log"), "euler": pooled("r5_swap_r4_vs_r5_euler.log"), "fused_stack": pooled("r5_swap_r4_vs_r5_wrapped.log"), "rk45": pooled("r5_swap_r4_vs_r5_rk45.log")}
 E["grid_barrier_vs_kernel_boundary (review round 4, Next 6)"] = {"commit": "af3c13a", "script": "scripts/grid_barrier_bench.hip", "result": rd("r5_grid_barrier_bench.log").strip()}
 E["ppo_all_reduce_in_the_epoch_graph (review round 4, Next 5)"] = js("ppo_rccl_graph.json")
+def _abtab(f):
+    out = {}
+    for ln in rd(f).split("\n"):
+        m = re.match(r"(\S+)\s+n=(\d+) rows=\d+ (.+?): gradient \+ reduce median\s+([\d.]+) us\s+min\s+([\d.]+) us", ln)
+        if m:
+            out.setdefault(m.group(3), {})[m.group(1)] = {"median_us": float(m.group(4)), "min_us": float(m.group(5))}
+    return out
+E["rk4_arithmetic_share (library dcb3613; scripts/jobs/r5_job33.sh: t_go's Newton loop cut to 6 / 4 iterations behind a throw-away switch, -DR6_ABLATE_REWARD; timing only)"] = pooled("r5_swap_tgo.log")
+E["ppo_gradient_launch_levers (library dcb3613; scripts/jobs/r5_job34.sh -DR6U_ABLATE=2 / =7, r5_job35.sh -fslp-vectorize on every unit; scripts/ppo_grad_ab.py)"] = {
+    "products_left_out (timing only, wrong gradients)": _abtab("r5_ppo_ablate.log"), "slp_vectoriser_on": _abtab("r5_ppo_slp.log")}
+_c4 = rd("r5_ppo_cfg4_mb.log")
+if "{" in _c4:
+    E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])
 json.dump(E, open(os.path.join(ROOT, "profiles", "r5_experiments.json"), "w"), indent=1)
 print("wrote profiles/r5_experiments.json:", list(E))
