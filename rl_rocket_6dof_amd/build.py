@@ -35,11 +35,17 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers() + [os.path.abspath(__file__)])
 
 
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-fno-math-errno",
          "-fno-slp-vectorize",   # packed-f32 (v_pk_*) SLP code is slower here: A/B 52 -> 46 us
+         # MFMA results land in vector registers unless the register allocator itself moves an accumulator to the accumulation file.
+         # Without it every matrix instruction of a kernel that needs more than 256 registers writes AGPRs, and whatever the VALU
+         # consumes (tanh, the loss, the f16 splits) is copied out first: ppo_grad_kernel's tile loop 3410 -> 3188 instructions
+         # (v_accvgpr_read 425 -> 169), gradient + reduce 38.1 -> 36.3 us; the rollout kernel 248 -> 171 / 304 -> 236 registers, 1-3 %.
+         # The step kernels hold no matrix instruction: their code objects are byte-identical with and without.
+         "-mllvm", "-amdgpu-mfma-vgpr-form",
          "-Wall", "-Wno-unused-function"]
 OBJ_DIR = os.path.join(CSRC, "build")
 
@@ -120,9 +126,9 @@ def _stamp_commit():
         root = os.path.join(HERE, "..")
         # the last commit that touched the library's sources (not HEAD: commits of docs, tests or scripts do not make a new library,
         # and profiles/ are stamped with this string)
-        rev = subprocess.run(["git", "-C", root, "log", "-1", "--format=%h", "--", "rl_rocket_6dof_amd/csrc", "include"], capture_output=True,
+        rev = subprocess.run(["git", "-C", root, "log", "-1", "--format=%h", "--", "rl_rocket_6dof_amd/csrc", "include", "rl_rocket_6dof_amd/build.py"], capture_output=True,
                              text=True, timeout=10).stdout.strip()
-        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "rl_rocket_6dof_amd/csrc", "include"], capture_output=True,
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "rl_rocket_6dof_amd/csrc", "include", "rl_rocket_6dof_amd/build.py"], capture_output=True,
                                text=True, timeout=10).stdout.strip()
         if rev:
             with open(COMMIT_FILE, "w") as f:

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(Shape<H1>::kBlock, (H1 > 64) ? R6P_WAVES128 : R6P_W
                                                             const uint64_t env_offset, const int deterministic,
                                                             const uint8_t* __restrict__ row_flags, const int flag_mask) {
     const uint64_t step_index = step_index_arg + (step_base ? *step_base : (uint64_t)0);
-    using Im = Image<H1, H2>;
+    using Im [[maybe_unused]] = Image<H1, H2>;
     constexpr int kBlock = Shape<H1>::kBlock, kWaves = Shape<H1>::kWaves;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;

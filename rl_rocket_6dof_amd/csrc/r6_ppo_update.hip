@@ -44,7 +44,7 @@ namespace r6u {
 constexpr int kBlock = 256, kWaves = 4;
 constexpr int kPitch = 36;                 // floats per row of the transposed tiles: 32 samples (even ones first, then the odd ones) + 4,
                                            // 16-byte aligned rows whose 16-float halves are read conflict-free as 4 x ds_read_b128
-constexpr int kP2 = 20;                    // floats per lane of the layer-2 weight images (16 used): a conflict-free ds_read_b128 pitch
+[[maybe_unused]] constexpr int kP2 = 20;   // floats per lane of the layer-2 weight images (16 used): a conflict-free ds_read_b128 pitch
 constexpr int kNumBlocks = 12;             // 32x32 slots of a partial set: dW2 (8) + dW1 (4; accumulated as two 16x16 blocks each, left half of the
                                            // slot), shared trunk [128, 64] or two MLPs (64, 64)
 constexpr int kFeatNet = 5 * 64;           // per net and layer-2 feature f: dW3^T[f][0..3] and db2[f], summed on the VALU with lane = feature
@@ -282,7 +282,8 @@ struct Args {
 template <int NETS, int H1, int H2, int OD>
 __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet net, const Args a, float* __restrict__ partial) {
     using Im = Image<NETS, H1, H2>;
-    constexpr int B1 = H1 / 32, B2 = H2 / 32, kP1 = Im::kP1;
+    constexpr int B1 = H1 / 32, B2 = H2 / 32;
+    [[maybe_unused]] constexpr int kP1 = Im::kP1;   // the fp32 forward's image pitch (R6U_F16_FWD=0)
     constexpr int kNetBlocks = B2 * B1 + B1;   // accumulator blocks of one net: dW2 [mb][ib], then dW1 [ib]
     static_assert(B2 == 2 && NETS * kNetBlocks == kNumBlocks && 5 * H2 == kFeatNet, "sized for a shared trunk [128, 64] or two MLPs (64, 64)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     // 16-byte loads per thread, each of them four consecutive k of one row = one ds_write_b128 of the layer-2 image and four
     // lanes' halves of a delta-chain fragment -- and the LDS writes follow in one go.  (As four dependent loops this took
     // 7.2 us of a 55 us launch: scripts/ppo_grad_fixed_cost.py.)
-    constexpr int kW2V = NETS * H2 * H1 / (4 * kBlock), kW1N = NETS * B1 * 64 * 8 / kBlock, kW3N = (Im::kW3 + kBlock - 1) / kBlock;
+    [[maybe_unused]] constexpr int kW2V = NETS * H2 * H1 / (4 * kBlock), kW1N = NETS * B1 * 64 * 8 / kBlock, kW3N = (Im::kW3 + kBlock - 1) / kBlock;
     static_assert(NETS * H2 * H1 % (4 * kBlock) == 0 && NETS * B1 * 64 * 8 % kBlock == 0 && Im::kB2 <= kBlock && H1 % 4 == 0, "whole rounds");
     constexpr int kFragN = NETS * B1 * B2 * 2 / kWaves;   // delta-chain fragments (chain, K-step) per wave
     static_assert(NETS * B1 * B2 * 2 % kWaves == 0, "whole rounds");

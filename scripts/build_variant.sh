@@ -13,7 +13,7 @@ C=$ROOT/rl_rocket_6dof_amd/csrc
 OUT=$C/variants
 OBJ=$C/build/variant_$NAME
 mkdir -p $OUT $OBJ
-FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-math-errno -fno-slp-vectorize -Wall -Wno-unused-function"
+FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -fno-math-errno -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wall -Wno-unused-function"   # = rl_rocket_6dof_amd/build.py FLAGS
 python3 -m rl_rocket_6dof_amd.build > /dev/null
 # a -D switch that is read outside r6_kernels.hip (r6_device.hpp is compiled into r6_rollout.hip too) with only r6_kernels.hip recompiled
 # would link mixed objects without a word (round-4 advice): such a switch turns --all on by itself
