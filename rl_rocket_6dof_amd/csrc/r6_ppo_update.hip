@@ -95,6 +95,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #if R6U_F16_DW2 && !R6U_F16_BWD
 #error "R6U_F16_DW2 uses the delta-chain scaling of R6U_F16_BWD"
 #endif
+// R6U_DW2_DIRECT (with R6U_F16_DW2): dW2's f16 products accumulate straight into the launch's sums.  delta2^T, dW2's A operand, is
+// scaled by ONE power of two per wave and net for the whole launch -- 2^(13 - e_base), e_base = floor(log2 max|delta2|) of the
+// wave's first non-zero tile + R6U_DW2_BASE_SHIFT -- instead of the tile's own factor, so every tile's products carry the same
+// factor and need neither a block of their own nor the join (16 x 8 fused multiply-adds per tile plus the copies between the
+// register files around them).  The factor leaves the sums once, after the tile loop.  Nothing in the tile loop branches on it: a
+// branch in the block loop splits its scheduling regions, and the allocator then spills a few hundred registers (tried: rescaling
+// the sums when a tile outgrows the factor; moving the excess to the a1 operand).  Instead the first tile's largest entry is placed
+// low, at [2^-3, 2^-2) -- f16 keeps 2^18 above it, and below it a hi + lo pair resolves 2^-24 absolute = 2^-21 of that entry
+// (subnormal halves: the matrix pipe keeps them; scripts/ppo_grad_accuracy.py: the same errors as with the entry at 2^13) --
+// and a tile more than 2^18 times the wave's first one saturates in this product (MODE.FP16_OVFL: +-65504, finite;
+// tests/test_gpu_ppo.py::test_fused_minibatch_grad_with_tiles_of_very_different_size).  The delta1 chains keep the tile's own
+// factor (their B operand, d2s).  =0 (default): a block per tile and the join.
+// MEASURED, NOT THE DEFAULT (round 5, scripts/jobs/r5_job39.sh - r5_job42.sh): the tile loop loses 200 of 3188 instructions and the
+// launch 0.2-0.5 us of 36 (65 536 samples), 1 us of 314 (2^20): stage E of the block loop, where the join ran, is bound by dW1's 16
+// fp32 matrix instructions once the join is gone, not by the vector work.  (A first timing build without the factor logic read
+// -12 us at 2^20: its sums ran to infinity, and the chip clocks higher on such data.)  Same accuracy as the default
+// (scripts/ppo_grad_accuracy.py), but a saturation regime the default does not have: off.
+#ifndef R6U_DW2_DIRECT
+#define R6U_DW2_DIRECT 0
+#endif
+#ifndef R6U_DW2_BASE_SHIFT
+#define R6U_DW2_BASE_SHIFT 16   // the first tile's largest delta2 entry goes to [2^(13 - shift), 2^(14 - shift)) = [2^-3, 2^-2): 2^18 of headroom above it, and
+                                // a hi + lo pair still resolves 2^-24 (f16 subnormals: the matrix pipe keeps them) = 2^-21 of that entry
+#endif
+#if R6U_DW2_DIRECT && !R6U_F16_DW2
+#error "R6U_DW2_DIRECT is a form of the f16 dW2 products"
+#endif
 #define R6U_FAST_STAGING R6U_F16_BWD   // images with f16 delta-chain fragments (either forward form): staged with every load in flight at once
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -281,6 +308,14 @@ struct Args {
 
 template <int NETS, int H1, int H2, int OD>
 __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet net, const Args a, float* __restrict__ partial) {
+#if R6U_DW2_DIRECT
+    // MODE.FP16_OVFL: a conversion to f16 that overflows gives +-65504, not infinity.  The only values that can get there are delta2^T
+    // entries of a tile 2^(15 - 13 + R6U_DW2_BASE_SHIFT) times the wave's first one and more, under the launch's factor: they saturate,
+    // finite, at no instruction (a v_med3 in front of the conversion would undo its fusion with the scaling multiply: +100 per tile)
+#ifndef R6U_NO_FP16_OVFL   // (timing experiments)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+#endif
+#endif
     using Im = Image<NETS, H1, H2>;
     constexpr int B1 = H1 / 32, B2 = H2 / 32;
     [[maybe_unused]] constexpr int kP1 = Im::kP1;   // the fp32 forward's image pitch (R6U_F16_FWD=0)
@@ -608,6 +643,12 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
     f32x16 acc[NETS * B2 * B1];                              // dW2 [net][mb][ib]
     f32x4 acc1[NETS * B1][2];                                // dW1 [net][ib]: two 16 x 16 blocks (rows 0..15, 16..31 of the 32-feature block)
     auto iW2 = [](int ni, int mb, int ib) __attribute__((always_inline)) { return (ni * B2 + mb) * B1 + ib; };
+#if R6U_DW2_DIRECT
+    constexpr int kNoBase = -1000;
+    int e_base[NETS];                                        // the launch-long factor of a net's dW2 sums is 2^(13 - e_base); kNoBase: no tile yet
+#pragma unroll
+    for (int ni = 0; ni < NETS; ++ni) e_base[ni] = kNoBase;
+#endif
     float f_w3[NETS][4], f_b2[NETS];                         // lane = layer-2 feature: dW3^T[lane][0..3], db2[lane]
 #pragma unroll
     for (int ni = 0; ni < NETS; ++ni) {
@@ -1028,6 +1069,19 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 const float scale = __uint_as_float((uint32_t)(127 + 13 - e) << 23);
                 d2_scale = scale;
                 d2_unscale = __uint_as_float((uint32_t)(127 - 13 + e) << 23);
+#if R6U_DW2_DIRECT
+                {
+                    const int eu = __builtin_amdgcn_readfirstlane(e);   // (the same in every lane: the maximum went round the wave)
+                    int eb = e_base[ni];
+                    if (eb == kNoBase && eu > -100) {   // the wave's first tile with a non-zero delta2 sets the launch's factor: its largest entry to [2^3, 2^4)
+                        eb = eu + R6U_DW2_BASE_SHIFT;
+                        e_base[ni] = eb;
+                    }
+                    int fe = (eb == kNoBase) ? 0 : 13 - eb;
+                    fe = fe < -126 ? -126 : (fe > 127 ? 127 : fe);
+                    d2_scale = __uint_as_float((uint32_t)(127 + fe) << 23);   // dTs' factor from here on; d2s above has the tile's own
+                }
+#endif
 #pragma unroll
                 for (int c = 0; c < B2; ++c) {
 #pragma unroll
@@ -1117,20 +1171,25 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // ---- C: dW2's products of this tile (its own block: delta2 went in scaled), delta1 finished meanwhile
+#if R6U_DW2_DIRECT   // dW2's products go straight into the launch's sums (delta2^T went in under the launch's factor)
+#define R6U_PART(mb) acc[iW2(ni, mb, ib)]
+#else
                 f32x16 part[B2];
 #pragma unroll
                 for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) part[mb][r] = 0.0f;
                 }
+#define R6U_PART(mb) part[mb]
+#endif
 #pragma unroll
                 for (int sk = 0; sk < 2; ++sk) {   // mfma3's three products, the two blocks alternating
 #pragma unroll
-                    for (int mb = 0; mb < B2; ++mb) part[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].lo, bas[sk].hi, part[mb], 0, 0, 0);
+                    for (int mb = 0; mb < B2; ++mb) R6U_PART(mb) = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].lo, bas[sk].hi, R6U_PART(mb), 0, 0, 0);
 #pragma unroll
-                    for (int mb = 0; mb < B2; ++mb) part[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].hi, bas[sk].lo, part[mb], 0, 0, 0);
+                    for (int mb = 0; mb < B2; ++mb) R6U_PART(mb) = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].hi, bas[sk].lo, R6U_PART(mb), 0, 0, 0);
 #pragma unroll
-                    for (int mb = 0; mb < B2; ++mb) part[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].hi, bas[sk].hi, part[mb], 0, 0, 0);
+                    for (int mb = 0; mb < B2; ++mb) R6U_PART(mb) = __builtin_amdgcn_mfma_f32_32x32x16_f16(dTs[mb][sk].hi, bas[sk].hi, R6U_PART(mb), 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1[r] = (d1[r] * d2_unscale) * fmaf(-a1[ni][ib][r], a1[ni][ib][r], 1.0f);
@@ -1155,11 +1214,13 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     acc1[ni * B1 + ib][0] = mfma16(t0[j], bxc[j], acc1[ni * B1 + ib][0]);
                     acc1[ni * B1 + ib][1] = mfma16(t1[j], bxc[j], acc1[ni * B1 + ib][1]);
                 }
+#if !R6U_DW2_DIRECT
 #pragma unroll
                 for (int mb = 0; mb < B2; ++mb) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[iW2(ni, mb, ib)][r] = fmaf(part[mb][r], d2_unscale, acc[iW2(ni, mb, ib)][r]);
                 }
+#endif
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1198,6 +1259,10 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     }
 #pragma unroll
                     for (int mb = 0; mb < B2; ++mb) {
+#if R6U_DW2_DIRECT
+#pragma unroll
+                        for (int sk = 0; sk < 2; ++sk) acc[iW2(ni, mb, ib)] = mfma3(dTs[mb][sk].hi, dTs[mb][sk].lo, bas[sk], acc[iW2(ni, mb, ib)]);
+#else
                         f32x16 part;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) part[r] = 0.0f;
@@ -1205,6 +1270,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                         for (int sk = 0; sk < 2; ++sk) part = mfma3(dTs[mb][sk].hi, dTs[mb][sk].lo, bas[sk], part);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[iW2(ni, mb, ib)][r] = fmaf(part[r], d2_unscale, acc[iW2(ni, mb, ib)][r]);
+#endif
                     }
 #else
 #pragma unroll
@@ -1277,6 +1343,23 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
         row_cur = row_next;
         row_next = row_after;
     }
+#if R6U_DW2_DIRECT
+    // the launch's factor leaves the dW2 sums (exact; a wave without a tile holds zeros)
+#pragma unroll
+    for (int ni = 0; ni < NETS; ++ni) {
+        int ue = (e_base[ni] == kNoBase) ? 0 : e_base[ni] - 13;
+        ue = ue > 127 ? 127 : ue;
+        const float up = __uint_as_float((uint32_t)(127 + ue) << 23);
+#pragma unroll
+        for (int mb = 0; mb < B2; ++mb) {
+#pragma unroll
+            for (int ib = 0; ib < B1; ++ib) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[iW2(ni, mb, ib)][r] *= up;
+            }
+        }
+    }
+#endif
 
     // ---- workgroup reduction: scalars, per-feature sums, then the accumulator blocks four at a time through the staging areas ----
 #ifdef R6U_STAMPS

@@ -133,6 +133,13 @@ def _abtab(f):
 E["rk4_arithmetic_share (library dcb3613; scripts/jobs/r5_job33.sh: t_go's Newton loop cut to 6 / 4 iterations behind a throw-away switch, -DR6_ABLATE_REWARD; timing only)"] = pooled("r5_swap_tgo.log")
 E["ppo_gradient_launch_levers (library dcb3613; scripts/jobs/r5_job34.sh -DR6U_ABLATE=2 / =7, r5_job35.sh -fslp-vectorize on every unit; scripts/ppo_grad_ab.py)"] = {
     "products_left_out (timing only, wrong gradients)": _abtab("r5_ppo_ablate.log"), "slp_vectoriser_on": _abtab("r5_ppo_slp.log")}
+E["mfma_results_in_vector_registers (-mllvm -amdgpu-mfma-vgpr-form; scripts/jobs/r5_job37.sh, r5_job38.sh; adopted in build.py at d6dc237)"] = {
+    "gradient_plus_reduce": _abtab("r5_ppo_vform.log"), "rollout_kernel_two_processes_per_library": [ln for ln in rd("r5_rollout_vform.log").split("\n") if ln.startswith("==") or "fused r6_rollout" in ln]}
+E["dw2_products_straight_into_the_launch_sums (-DR6U_DW2_DIRECT=1, off by default; scripts/jobs/r5_job39.sh - r5_job42.sh)"] = {
+    "timing_build_with_sums_running_to_infinity (misleading: the chip clocks higher on such data)": _abtab("r5_ppo_direct.log"),
+    "the_exact_form (direct = shift 16, sh10 = first tile's largest entry at 2^3, nodirect = default)": _abtab("r5_ppo_direct_ab.log"),
+    "placement_of_the_first_tile (sh0 .. sh16)": _abtab("r5_ppo_shift.log"), "with_and_without_MODE.FP16_OVFL": _abtab("r5_ppo_ovfl.log"),
+    "accuracy_against_float64_autograd": [ln for ln in rd("r5_ppo_direct_acc.log").split("\n") if "autograd" in ln]}
 _c4 = rd("r5_ppo_cfg4_mb.log")
 if "{" in _c4:
     E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])

@@ -199,6 +199,53 @@ def test_fused_minibatch_grad_matches_autograd(obs_dim, n_rows, n_mb, norm_adv, 
           f"{max(float((p.grad - g).abs().max()) / max(float(g.abs().max()), 1e-12) for p, g in zip(params, g_ref)):.2e}")
 
 
+@pytest.mark.parametrize("arch,shared", [((128, 64), True), ((64, 64), False)])
+@pytest.mark.parametrize("log2_ratio", [15, 26])
+def test_fused_minibatch_grad_with_tiles_of_very_different_size(log2_ratio, arch, shared):
+    """The f16 products of the backward pass scale delta2 by a power of two PER TILE (r6_ppo_update.hip, R6U_F16_BWD / R6U_F16_DW2), so
+    tiles of any size relative to each other keep full accuracy.  Here every wave's first tile has gradients 2^15 (2^26) times smaller
+    than its second one: 65 536 ordered rows, the first half scaled down -- advantages and value errors alike; every gradient within
+    2e-5 of its tensor's largest entry as always.  (The measured-and-dropped R6U_DW2_DIRECT form, one factor per wave and launch,
+    passes the first case and saturates in the second: this test is what it would have to be changed for.)"""
+    import torch
+
+    from rl_rocket_6dof_amd.ppo import ActorCritic, FusedMinibatchGrad
+
+    torch.manual_seed(3)
+    dev, od, n = "cuda", 13, 65536
+    pol = ActorCritic(od, 3, arch, log_std_init=-0.3, shared_trunk=shared).to(dev)
+    with torch.no_grad():
+        pol.pi[-1].weight.mul_(30.0)
+        pol.log_std.copy_(torch.tensor([-0.4, 0.2, -1.0]))
+    obs = torch.randn(n, od, device=dev) * 0.7
+    with torch.no_grad():
+        mean_all, v_all = pol._forward(obs)
+    action = (mean_all + torch.randn(n, 3, device=dev) * pol.log_std.exp()).detach()
+    old_logp = pol._logp(mean_all, action).detach() + torch.randn(n, device=dev) * 0.1
+    adv, ret = torch.randn(n, device=dev) * 2 + 0.3, torch.randn(n, device=dev)
+    small = 2.0 ** -log2_ratio
+    adv[: n // 2] *= small
+    ret[: n // 2] = (v_all.reshape(-1)[: n // 2] + (ret[: n // 2] - v_all.reshape(-1)[: n // 2]) * small).detach()
+    mb = torch.arange(n, device=dev)
+    clip, vf, ec = 0.2, 0.5, 0.01
+    values, logp, entropy = pol.evaluate(obs, action)
+    ratio = torch.exp(logp - old_logp)
+    loss = -torch.min(adv * ratio, adv * ratio.clamp(1 - clip, 1 + clip)).mean() - ec * entropy.mean() + vf * torch.nn.functional.mse_loss(ret, values)
+    params = list(pol.parameters())
+    g_ref = torch.autograd.grad(loss, params)
+    for p in params:
+        p.grad = None
+    FusedMinibatchGrad(pol)(obs, action, old_logp, adv, ret, mb, None, clip, vf, ec)
+    torch.cuda.synchronize()
+    worst = {}
+    for (name, p), gr in zip(pol.named_parameters(), g_ref):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        scale, err = float(gr.abs().max()), float((p.grad - gr).abs().max())
+        worst[name] = err / max(scale, 1e-12)
+        assert err <= 2e-5 * max(scale, 1e-7) + 1e-10, f"{name}: max abs err {err:.3e} vs scale {scale:.3e}"
+    print(f"[tiles 2^{log2_ratio} apart, {arch} shared={shared}] worst relative gradient error " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
 def test_fused_adam_clip_step_matches_torch():
     """r6_adam_clip_step on the flat parameter / gradient / moment arrays against torch.nn.utils.clip_grad_norm_ +
     torch.optim.Adam(eps=1e-5) on the same tensors, several steps, with the clip active and inactive and a log-std floor."""
