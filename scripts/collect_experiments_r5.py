@@ -140,6 +140,11 @@ E["dw2_products_straight_into_the_launch_sums (-DR6U_DW2_DIRECT=1, off by defaul
     "the_exact_form (direct = shift 16, sh10 = first tile's largest entry at 2^3, nodirect = default)": _abtab("r5_ppo_direct_ab.log"),
     "placement_of_the_first_tile (sh0 .. sh16)": _abtab("r5_ppo_shift.log"), "with_and_without_MODE.FP16_OVFL": _abtab("r5_ppo_ovfl.log"),
     "accuracy_against_float64_autograd": [ln for ln in rd("r5_ppo_direct_acc.log").split("\n") if "autograd" in ln]}
+_pp = [ln for ln in rd("r5_preroll_probe.log").split("\n") if ln.startswith("{")]
+if _pp:
+    E["preroll_length_against_the_20_launch_sample (scripts/preroll_probe.py, scripts/jobs/r5_job43.sh; library fa2a3e3)"] = {
+        "what": "from an idle chip: P seconds of stepping as bench.py's pre-roll does, 5 warm-up launches, barrier, 20 launches between two events, then 1000 launches for the steady median of the same moment; 8 trials per P in random order",
+        "by_preroll_seconds": json.loads(_pp[-1]), "reading": "9 of 48 samples above 1.06 x their own steady median (19 %: the share of 20-launch windows a continuous run has in slow episodes); 0 of 8 at 1 s, 3 of 8 at 4 s"}
 _c4 = rd("r5_ppo_cfg4_mb.log")
 if "{" in _c4:
     E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])
