@@ -217,6 +217,9 @@ def parse_args(argv=None):
                     help="untimed stepping by TIME (not by count) after the burn-in and before --warmup: the chip's clocks and the "
                          "launch pipeline are in their steady state when the contract's W + K steps run (2000 burn-in launches are "
                          "75 ms; the first 30 ms of a process run 32 -> 53 -> 36 us per launch, gpurun_out/r5_trace_driver_shape_summary.json)")
+    ap.add_argument("--preroll-batch", type=int, default=4,
+                    help="launches between two synchronizes of the pre-roll (4 = 92 %% duty: the timed region does not start at the chip's "
+                         "power limit; 200 = round 5's first form, 99 %% duty: see preroll())")
     ap.add_argument("--steady-launches", type=int, default=2000,
                     help="launches of the `steady` record taken right AFTER the contract's timed region on the same env, in chunks of "
                          "--steady-chunk launches (0 = skip): the distribution a K-launch sample is drawn from")
@@ -364,7 +367,7 @@ def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: floa
         "data": "synthetic",
         "config": {"workload": f"{n} envs/GPU x {world} GPU, {args.integrator} dt={dt} fp32, {args.variant} "
                                f"Rocket6DOF.step, random actions, auto-reset, {args.burnin} burn-in steps + {args.preroll_seconds:g} s of "
-                               f"untimed stepping before the {args.warmup} warm-up and {args.steps} timed steps, "
+                               f"untimed stepping (a synchronize every {args.preroll_batch} launches) before the {args.warmup} warm-up and {args.steps} timed steps, "
                                f"{args.k} env step(s) per launch",
                    "envs_total": total, "integrator": args.integrator, "dt": dt, "variant": args.variant,
                    "steps_per_launch": args.k, "bytes_per_env_step": bytes_per, "parallelism": f"env-shard x{world}",
@@ -410,20 +413,25 @@ def make_pool(torch, n, k, count, dev, seed):
     return [(torch.rand(shape, generator=gen, device=dev) * 2 - 1).contiguous() for _ in range(count)]
 
 
-def preroll(env, pool, seconds: float, k: int, sync) -> int:
-    """Untimed stepping for `seconds` of wall time (launches in batches of 200 with a synchronize between them); returns the
-    number of env steps issued."""
+def preroll(env, pool, seconds: float, k: int, sync, batch: int = 4) -> int:
+    """Untimed stepping for `seconds` of wall time, in batches of `batch` launches with a synchronize between them; returns the number
+    of env steps issued.  Why small batches (scripts/preroll_duty_probe.py): behind 1 s of stepping in batches of
+    200 (99 % duty) the chip is at its power limit, and a 20-launch timed region started there sat in a clock dip in 3 of 12 trials
+    (35.5 ... 43.1 us); behind 1 s in batches of 4 (92 % duty, 25 000 launches) it never did in 12 (35.4 ... 36.7 us = 0.97 ... 1.01 x the
+    steady median measured right behind it), and behind one launch per synchronize (70 % duty) neither -- but there the dips arrive
+    two to four chunks later.  The timed region itself is back to back, as the contract says; a 2000-step region meets the dips
+    anyway, and the `steady` record shows them."""
     done, npool = 0, len(pool)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         if k <= 1:
-            for j in range(200):
+            for j in range(batch):
                 env.step_async(pool[j % npool])
-            done += 200
+            done += batch
         else:
-            for j in range(max(1, 200 // k)):
+            for j in range(max(1, batch // k)):
                 env.step_k(pool[j % npool], out=env._bench_out)
-            done += max(1, 200 // k) * k
+            done += max(1, batch // k) * k
         sync()
     return done
 
@@ -871,7 +879,7 @@ def main(argv=None):
 
     stream = torch.cuda.current_stream(dev)
     if args.preroll_seconds > 0:
-        preroll(env, pool, args.preroll_seconds, args.k, lambda: torch.cuda.synchronize(dev))     # untimed, by time
+        preroll(env, pool, args.preroll_seconds, args.k, lambda: torch.cuda.synchronize(dev), args.preroll_batch)     # untimed, by time
     timed_loop(env, pool, max(args.warmup, args.k), args.k, barrier, stream, torch)        # W untimed steps
     wall, kernel_ms = timed_loop(env, pool, args.steps, args.k, barrier, stream, torch)    # EXACTLY K timed steps
 

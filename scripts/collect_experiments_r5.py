@@ -145,6 +145,13 @@ if _pp:
     E["preroll_length_against_the_20_launch_sample (scripts/preroll_probe.py, scripts/jobs/r5_job43.sh; library fa2a3e3)"] = {
         "what": "from an idle chip: P seconds of stepping as bench.py's pre-roll does, 5 warm-up launches, barrier, 20 launches between two events, then 1000 launches for the steady median of the same moment; 8 trials per P in random order",
         "by_preroll_seconds": json.loads(_pp[-1]), "reading": "9 of 48 samples above 1.06 x their own steady median (19 %: the share of 20-launch windows a continuous run has in slow episodes); 0 of 8 at 1 s, 3 of 8 at 4 s"}
+_pd = [ln for ln in rd("r5_preroll_duty.log").split("\n") if ln.startswith("{")]
+if _pd:
+    E["preroll_duty_cycle_against_the_20_launch_sample (scripts/preroll_duty_probe.py, scripts/jobs/r5_job44.sh)"] = {
+        "modes": "full = batches of 200 launches between synchronizes (bench.py until 2970fd0), sync4 / sync1 = a synchronize every 4 / every launch, gap = + 30 us of host sleep",
+        "by_mode": json.loads(_pd[-1]), "trials": [ln for ln in rd("r5_preroll_duty.log").split("\n") if "launches in 1 s" in ln]}
+if rd("r5_driver_shape_b4.log"):
+    E["driver_shape_with_the_batch_4_preroll (scripts/jobs/r5_job45.sh; eight + four fresh processes on one box, then the default command)"] = rd("r5_driver_shape_b4.log").strip().split("\n")
 _c4 = rd("r5_ppo_cfg4_mb.log")
 if "{" in _c4:
     E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])
