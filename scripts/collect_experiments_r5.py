@@ -152,6 +152,10 @@ if _pd:
         "by_mode": json.loads(_pd[-1]), "trials": [ln for ln in rd("r5_preroll_duty.log").split("\n") if "launches in 1 s" in ln]}
 if rd("r5_driver_shape_b4.log"):
     E["driver_shape_with_the_batch_4_preroll (scripts/jobs/r5_job45.sh; eight + four fresh processes on one box, then the default command)"] = rd("r5_driver_shape_b4.log").strip().split("\n")
+E["compiler_scheduling_strategies_for_the_step_kernels (scripts/jobs/r5_job46.sh, r5_job47.sh; none kept)"] = {
+    "rk4_raw_first_session (max-ilp, amdgpu-trackers, max-memory-clause)": pooled("r5_swap_sched.log"),
+    "amdgpu_trackers": {"rk4_raw": pooled("r5_swap_trk_rk4.log"), "euler": pooled("r5_swap_trk_euler.log"), "fused_stack": pooled("r5_swap_trk_wrapped.log"),
+                        "rk45": pooled("r5_swap_trk_rk45.log"), "rk4_2^23_envs": pooled("r5_swap_trk_2p23.log"), "step_k (base, trackers, base, trackers)": kbench("r5_kstep_trk.log")}}
 _c4 = rd("r5_ppo_cfg4_mb.log")
 if "{" in _c4:
     E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])
