@@ -119,6 +119,28 @@ def build_test_hooks(force: bool = False, verbose: bool = True) -> str:
 COMMIT_FILE = os.path.join(CSRC, "BUILD_COMMIT")
 
 
+def device_code_digest() -> str:
+    """12 hex digits over the disassembly of the gfx950 code objects of the four release units: two libraries with the same digest run the
+    same device code whatever commits their sources carry (a comment, a renamed macro).  Empty when the LLVM tools are missing."""
+    import hashlib
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    h = hashlib.md5()
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            for src in SOURCES:
+                obj = os.path.join(OBJ_DIR, "release", src.replace(".hip", ".o"))
+                subprocess.run([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={td}/fat.bin", obj, f"{td}/dummy"], check=True, capture_output=True)
+                subprocess.run([f"{llvm}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={td}/fat.bin", f"--output={td}/co",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True, capture_output=True)
+                dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", f"{td}/co"], check=True, capture_output=True, text=True).stdout
+                h.update("\n".join(ln for ln in dis.splitlines() if "file format" not in ln).encode())
+        return h.hexdigest()[:12]
+    except Exception:
+        return ""
+
+
 def _stamp_commit():
     """Records the source commit next to the library (git-ignored; travels with the .so to machines without .git, where
     bench.py reports it)."""
@@ -131,8 +153,9 @@ def _stamp_commit():
         dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "rl_rocket_6dof_amd/csrc", "include", "rl_rocket_6dof_amd/build.py"], capture_output=True,
                                text=True, timeout=10).stdout.strip()
         if rev:
+            code = device_code_digest()
             with open(COMMIT_FILE, "w") as f:
-                f.write(rev + ("+dirty" if dirty else "") + "\n")
+                f.write(rev + ("+dirty" if dirty else "") + (f" code:{code}" if code else "") + "\n")
     except Exception:
         pass
 

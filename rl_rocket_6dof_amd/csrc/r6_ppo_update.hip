@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                 {
                     const int eu = __builtin_amdgcn_readfirstlane(e);   // (the same in every lane: the maximum went round the wave)
                     int eb = e_base[ni];
-                    if (eb == kNoBase && eu > -100) {   // the wave's first tile with a non-zero delta2 sets the launch's factor: its largest entry to [2^3, 2^4)
+                    if (eb == kNoBase && eu > -100) {   // the wave's first tile with a non-zero delta2 sets the launch's factor: its largest entry to [2^(13 - shift), 2^(14 - shift))
                         eb = eu + R6U_DW2_BASE_SHIFT;
                         e_base[ni] = eb;
                     }
@@ -1199,6 +1199,7 @@ __global__ __launch_bounds__(kBlock, 1) void ppo_grad_kernel(const R6PolicyNet n
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#undef R6U_PART
                 // ---- D: delta1 takes the a1 block's place (its readers -- the request of stage A -- are done)
                 wave_sync();
 #pragma unroll
