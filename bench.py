@@ -542,6 +542,48 @@ def two_groups_side_measurement(torch, dev, cfg, rounds: int = 9, steps: int = 4
     return out
 
 
+def single_env_side_measurement(torch, dev, steps: int = 1000, repeats: int = 3) -> dict:
+    """BASELINE configs[0]: ONE env stepped from the host, 1000 random-action steps with a reset at every episode end -- the
+    reference's own way of running (test_6DOF_environment.py:23-35, test_6DOF_simulator.py:3-7), through the single-env drop-ins
+    `Rocket6DOF` / `Simulator6DOF` (rocket_env.py of this package: one lane of one wave does the work; a step is one launch,
+    two small copies through pinned images and one synchronisation).  Latency-bound by construction; a side figure."""
+    import numpy as np
+
+    from rl_rocket_6dof_amd import Rocket6DOF, Simulator6DOF, default_env_config
+    rng = np.random.RandomState(0)
+
+    def run(env, k):
+        env.reset()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            if env.step(rng.uniform(-1, 1, 3).astype(np.float32))[2]:
+                env.reset()
+        return k / (time.perf_counter() - t0)
+
+    out = {"label": "BASELINE configs[0]: one env, host-driven, 1000 random-action steps, dt 0.1; env-steps/s (median of "
+                    f"{repeats}); the reference's Python on one Xeon core of the survey container: 730/s (BASELINE.md section 2)",
+           "steps": steps, "reference_python_steps_per_s": 730.0}
+    for integ in ("rk4", "rk45"):
+        env = Rocket6DOF(**default_env_config(), device=dev, integrator=integ)
+        run(env, 200)
+        out[f"rocket6dof_{integ}_steps_per_s"] = float(np.median([run(env, steps) for _ in range(repeats)]))
+        env.close()
+    ic = [100, 100, 100, 0, 3, 4, 1, 1, 0, 0, 0, 0, 0, 50e3]
+    sim = Simulator6DOF(ic, dt=0.1, device=dev)
+
+    def run_sim(k):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            sim.state = np.asarray(ic, dtype=np.float64)
+            sim.step([0.0, 0.0, 1.0])
+        del sim.states[1:], sim.actions[1:], sim.times[1:]
+        return k / (time.perf_counter() - t0)
+
+    run_sim(200)
+    out["simulator6dof_rk4_steps_per_s"] = float(np.median([run_sim(steps) for _ in range(repeats)]))
+    return out
+
+
 def ppo_side_measurement(torch, dev, iters: int = 5, warm: int = 3) -> dict:
     """SURVEY section 8 (f2), the loop main_6DOF.py:107-139 drives through SB3: PPO iterations of the on-device trainer at the
     configuration of examples/train_ppo.py -- rollout + GAE, then 10 epochs x 16 minibatch steps -- timed whole (wall clock around
@@ -947,6 +989,7 @@ def main(argv=None):
                 label="2^20 envs, in-kernel adaptive RK45 (scipy's step control, the reference's own integrator: simulator.py:83-88), dt 0.1, raw step: "
                       "bound by arithmetic (8-20 RHS evaluations per env step, the wave follows its slowest lane), not by HBM")
             extras["two_groups"] = two_groups_side_measurement(torch, dev, cfg)
+            extras["configs0"] = single_env_side_measurement(torch, dev)
             extras["ppo_training"] = ppo_side_measurement(torch, dev)
             extras["ppo_configs4"] = ppo_configs4_side_measurement(torch, dev)
         if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:

@@ -80,6 +80,25 @@ class LazyInfos(Sequence):
     def __len__(self):
         return self._env.num_envs
 
+    @classmethod
+    def from_host(cls, env: "BatchedRocket6DOF", views: dict) -> "LazyInfos":
+        """The ``infos`` of the step whose outputs ``env.fetch_host()`` just brought over (copies of the pinned image: the
+        next fetch overwrites it) -- no further device access."""
+        self = cls(env)
+        h = {"done": views["done"].astype(bool)}
+        h["flags"] = views["flags"].copy() if "flags" in views else None
+        idx = np.nonzero(h["done"])[0]
+        h["done_idx"] = {int(k): j for j, k in enumerate(idx)}
+        h["final_obs"] = h["fin_return"] = h["fin_length"] = None
+        if len(idx) and env.auto_reset:
+            h["final_obs"] = views["final_obs"][idx]
+            if "fin_return" in views and "fin_length" in views:
+                h["fin_return"], h["fin_length"] = views["fin_return"][idx], views["fin_length"][idx]
+        h["terms"] = views["terms"][:, : env.num_envs].copy() if "terms" in views else None
+        h["t"] = round(time.time() - env._t_start, 6)
+        self._host = h
+        return self
+
     def materialize(self) -> "LazyInfos":
         self._snapshot()
         return self
@@ -151,8 +170,13 @@ class BatchedRocket6DOF(VecEnv):
                  auto_reset: bool = True, seed: Optional[int] = None, env_offset: int = 0,
                  record_terms: bool = False, record_flags: bool = True, track_episodes: bool = True,
                  numpy_io: bool = False, lib_path: Optional[str] = None, reward_annealing: bool = False,
-                 vertical_attitude_reward=None, record_nfev: bool = False, groups: int = 1, group_sync: str = "caller"):
-        """``groups`` > 1 (round 5): ``step_async`` steps the batch as that many contiguous env groups, each with its own ``r6_step``
+                 vertical_attitude_reward=None, record_nfev: bool = False, groups: int = 1, group_sync: str = "caller",
+                 host_mirror: bool = False):
+        """``host_mirror`` (small batches read back every step, e.g. the single-env drop-in): every per-env buffer is a view of ONE
+        device allocation with a pinned host copy of the same layout; ``fetch_host()`` brings a whole step's outputs over in one
+        copy and one synchronisation instead of one round trip per tensor.  The kernels see the same buffers either way.
+
+        ``groups`` > 1 (round 5): ``step_async`` steps the batch as that many contiguous env groups, each with its own ``r6_step``
         launch on a stream the env owns -- launches of ONE stream serialise, launches of two streams overlap, and one group's
         ramp (first loads) and tail (last tiles, reset drain) then run under the other group's bulk.  Results do not depend on
         it: envs are independent and the reset RNG is keyed by the global env index (the sharding invariance of section 5 of
@@ -223,6 +247,10 @@ class BatchedRocket6DOF(VecEnv):
         self._join_events = [torch.cuda.Event() for _ in range(self.groups)] if self.groups > 1 else []
         self._groups_in_flight = False
 
+        self._arena = self._host_arena = None
+        self._host_views: dict = {}
+        if host_mirror:
+            self._build_host_mirror()
         self._buf = R6Buffers()
         self._gbufs = []
         self._step_base = None
@@ -244,6 +272,47 @@ class BatchedRocket6DOF(VecEnv):
         b.nfev = _ptr(self.nfev)
         if self.groups > 1 and hasattr(self, "_group_bounds"):
             self._gbufs = [self._group_buffers(b, g) for g in range(self.groups)]   # per-step work: only their action pointers move
+
+    _MIRRORED = ("state", "epconst", "_act", "obs", "reward", "done", "flags", "terms", "nfev", "final_obs", "ep_step", "ep_return",
+                 "fin_return", "fin_length")
+
+    def _build_host_mirror(self) -> None:
+        """Moves the (still zero) per-env buffers into one device allocation, 256-byte aligned each, next to a pinned host
+        image of the same layout with numpy views of every buffer (``_host_views``)."""
+        plan, off = [], 0
+        for name in self._MIRRORED:
+            t = getattr(self, name)
+            if t is not None:
+                nbytes = t.numel() * t.element_size()
+                plan.append((name, off, nbytes, t.dtype, tuple(t.shape)))
+                off += (nbytes + 255) // 256 * 256
+        self._arena = torch.zeros((off,), dtype=torch.uint8, device=self.device)
+        self._host_arena = torch.zeros((off,), dtype=torch.uint8).pin_memory()
+        self._host_action = torch.zeros((self.num_envs, ACTION_DIM), dtype=torch.float32).pin_memory()
+        for name, o, nbytes, dtype, shape in plan:
+            setattr(self, name, self._arena[o:o + nbytes].view(dtype).view(shape))
+            self._host_views[name] = self._host_arena[o:o + nbytes].view(dtype).view(shape).numpy()
+
+    def fetch_host(self) -> dict:
+        """``host_mirror=True``: one device->host copy of every per-env buffer behind whatever the current stream holds, one
+        synchronisation; returns numpy views of the pinned image, keyed by buffer name (valid until the next call)."""
+        if self._arena is None:
+            raise RuntimeError("fetch_host() needs an env built with host_mirror=True")
+        self.join_groups()
+        self._host_arena.copy_(self._arena, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._host_views
+
+    def step_host(self, actions) -> dict:
+        """``host_mirror=True``: one step driven from the host -- the (N, 3) actions go up through a pinned buffer, every output
+        comes back through ``fetch_host()``: one launch, two small copies and one synchronisation per step."""
+        if self._arena is None:
+            raise RuntimeError("step_host() needs an env built with host_mirror=True")
+        self._host_action.numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, ACTION_DIM)
+        self._act.copy_(self._host_action, non_blocking=True)
+        self.step_async(self._act)
+        self._pending = None
+        return self.fetch_host()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

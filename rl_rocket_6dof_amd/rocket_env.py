@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .batched_env import BatchedRocket6DOF, _ptr
+from .batched_env import BatchedRocket6DOF, LazyInfos, _ptr
 from .compat import Box, Env
 from .params import (ACTION_NAMES, MAX_GIMBAL, MAX_THRUST, STATE_DIM, STATE_NAMES, R6Params, auto_substeps,
                      default_env_config)
@@ -65,28 +65,45 @@ class Simulator6DOF:
         self._p.dt = float(dt)
         self._p.integrator = {"euler": 0, "rk4": 1, "rk45": 2}[integrator]
         self._p.n_substeps = int(auto_substeps(dt) if n_substeps is None else n_substeps)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self._ld = 64
-        self._state = torch.zeros((STATE_DIM, self._ld), **f32)
-        self._epconst = torch.zeros((2, self._ld), **f32)
-        self._epconst[0, 0] = self.m
-        self._u = torch.zeros((1, 3), **f32)
-        self._dy = torch.zeros((STATE_DIM, self._ld), **f32)
-        self._status = torch.zeros((1,), dtype=torch.uint8, device=self.device)
+        # One device image [state 14 x ld | epconst 2 x ld | u | status | dy 14 x ld] (rows of ld = 64 floats) next to a pinned host
+        # image of the same layout: a step is one upload (state, u), one launch, one download (state, status) and one
+        # synchronisation -- the state lives on the host between calls, as in the reference (scripts overwrite `SIM.state`).
+        self._ld = ld = 64
+        rows = STATE_DIM + 2 + 1 + 1 + STATE_DIM
+        self._dev = torch.zeros((rows, ld), dtype=torch.float32, device=self.device)
+        self._host = torch.zeros((rows, ld), dtype=torch.float32).pin_memory()
+        self._h = self._host.numpy()
+        self._state, self._epconst = self._dev[:STATE_DIM], self._dev[STATE_DIM:STATE_DIM + 2]
+        self._u = self._dev[STATE_DIM + 2, :3].view(1, 3)
+        self._status = self._dev[STATE_DIM + 3].view(torch.uint8)[:1]
+        self._dy = self._dev[STATE_DIM + 4:]
+        self._h[STATE_DIM, 0] = self.m
+        self._dev.copy_(self._host)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _upload(self, state, u):
+        h = self._h
+        h[:STATE_DIM, 0] = np.asarray(state, dtype=np.float32)
+        h[STATE_DIM + 2, :3] = np.asarray(u, dtype=np.float32)
+        up = STATE_DIM + 3
+        self._dev[:up].copy_(self._host[:up], non_blocking=True)
+
+    def _download(self, lo, hi):
+        self._host[lo:hi].copy_(self._dev[lo:hi], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+
     def step(self, u):
         """simulator.py:69-104 -- returns (state[14], status); status 1 = ground event."""
-        self._state[:, 0] = torch.as_tensor(np.asarray(self.state, dtype=np.float32), device=self.device)
-        self._u[0] = torch.as_tensor(np.asarray(u, dtype=np.float32), device=self.device)
         with torch.cuda.device(self.device):
+            self._upload(self.state, u)
             rc = self.lib.r6_sim_step(C.byref(self._p), _ptr(self._state), _ptr(self._epconst), _ptr(self._u),
                                       _ptr(self._status), 1, self._ld, self._stream())
-        _lib.check(rc, "r6_sim_step", self.lib)
-        self.state = self._state[:, 0].cpu().numpy().astype(np.float64)
-        status = int(self._status.item())
+            _lib.check(rc, "r6_sim_step", self.lib)
+            self._download(0, STATE_DIM + 4)
+        self.state = self._h[:STATE_DIM, 0].astype(np.float64)
+        status = int(self._h[STATE_DIM + 3].view(np.uint8)[0])
         self.t = round(self.t + self.timestep, 3)                  # simulator.py:92
         self.times.append(self.t)
         self.states.append(self.state)
@@ -95,13 +112,13 @@ class Simulator6DOF:
 
     def RHS(self, t, state, u):
         """simulator.py:106-143."""
-        self._state[:, 0] = torch.as_tensor(np.asarray(state, dtype=np.float32), device=self.device)
-        self._u[0] = torch.as_tensor(np.asarray(u, dtype=np.float32), device=self.device)
         with torch.cuda.device(self.device):
+            self._upload(state, u)
             rc = self.lib.r6_rhs(C.byref(self._p), _ptr(self._state), _ptr(self._epconst), _ptr(self._u),
                                  _ptr(self._dy), 1, self._ld, self._stream())
-        _lib.check(rc, "r6_rhs", self.lib)
-        return self._dy[:, 0].cpu().numpy().astype(np.float64)
+            _lib.check(rc, "r6_rhs", self.lib)
+            self._download(STATE_DIM + 4, 2 * STATE_DIM + 4)
+        return self._h[STATE_DIM + 4:, 0].astype(np.float64)
 
     def get_thrust_vector_inertial(self):
         """simulator.py:177-186 -- R(q of states[-1]) @ T_B(actions[-1])  (host-side helper)."""
@@ -151,8 +168,9 @@ class Rocket6DOF(Env):
         }
         self.state_names = list(STATE_NAMES)
         self.action_names = list(ACTION_NAMES)
+        # host_mirror: all of a step's outputs come back in ONE device->host copy (one env is read back every step)
         self._vec = BatchedRocket6DOF(1, cfg, device=device, integrator=integrator, n_substeps=n_substeps,
-                                      auto_reset=False, record_terms=True, record_flags=True, seed=seed)
+                                      auto_reset=False, record_terms=True, record_flags=True, seed=seed, host_mirror=True)
         spec = self._vec.spec
         self.ICMean, self.ICRange = spec.ic_mean, spec.ic_range
         self.timestep = timestep
@@ -182,11 +200,12 @@ class Rocket6DOF(Env):
         return [seed]
 
     def _begin_episode(self, obs):
-        ic = self._vec.get_state()[0].cpu().numpy()
+        h = self._vec.fetch_host()
+        ic = h["state"][:, 0].copy()
         self.initial_condition = ic
         self.state = ic
         self.SIM = _SimView(ic, self.timestep)
-        return np.asarray(obs[0].cpu().numpy(), dtype=np.float32)
+        return h["obs"][0].copy()
 
     def reset(self):
         """rocket_env.py:180-199."""
@@ -208,17 +227,17 @@ class Rocket6DOF(Env):
         """rocket_env.py:201-231."""
         a = np.asarray(normalized_action, dtype=np.float32).reshape(1, 3)
         self.action = self._denormalize_action(a[0])
-        obs, rew, done, infos = self._vec.step(torch.as_tensor(a))
-        self.state = self._vec.get_state()[0].cpu().numpy().astype(np.float64)
+        h = self._vec.step_host(a)
+        self.state = h["state"][:, 0].astype(np.float64)
         sim = self.SIM
         sim.state = self.state
         sim.t = round(sim.t + self.timestep, 3)
         sim.times.append(sim.t)
         sim.states.append(self.state)
         sim.actions.append(self.action)
-        info = infos[0]
+        info = LazyInfos.from_host(self._vec, h)[0]
         info.update(state_history=sim.states, action_history=sim.actions, timesteps=sim.times)
-        return (np.asarray(obs[0].cpu().numpy(), dtype=np.float32), float(rew[0].item()), bool(done[0].item()), info)
+        return h["obs"][0].copy(), float(h["reward"][0]), bool(h["done"][0]), info
 
     def get_state(self):
         return self.state

@@ -829,3 +829,44 @@ def test_rk45_fuzz_vs_scipy_oracle(torch_cuda, cfg, P):
         assert bad_status == 0
         assert errs.max() < 1e-4 and (errs < 1e-5).mean() >= 0.99
         assert same_nfev >= 0.9 * n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,kw", [(1, dict(auto_reset=False, record_terms=True)),
+                                  (200, dict(auto_reset=True, record_terms=True, max_episode_steps=40, remove_mass=True, clip_reward=(-1, 100))),
+                                  (4096, dict(auto_reset=True, record_terms=False, record_nfev=True, integrator="rk45"))])
+def test_host_mirror_changes_nothing(torch_cuda, cfg, n, kw):
+    """``host_mirror=True`` (every per-env buffer a view of one device allocation + one pinned image; the single-env drop-in
+    steps through it): the same bytes in every buffer as the separately allocated env, step by step, and ``infos`` built
+    from the pinned image equal to the ones read from the device."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+    from rl_rocket_6dof_amd.batched_env import LazyInfos
+
+    a = BatchedRocket6DOF(n, cfg, seed=5, **kw)
+    b = BatchedRocket6DOF(n, cfg, seed=5, host_mirror=True, **kw)
+    a.reset()
+    b.reset()
+    rng = np.random.RandomState(3)
+    for k in range(60):
+        act = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        _, _, _, infos = a.step(torch.as_tensor(act, device=a.device))
+        h = b.step_host(act)
+        for name in b._MIRRORED:
+            ta = getattr(a, name)
+            if name == "_act" or ta is None:
+                continue
+            assert np.array_equal(ta.cpu().numpy(), h[name], equal_nan=True), (name, k)
+        hi = LazyInfos.from_host(b, h)
+        for i in (0, n // 2, n - 1):
+            x, y = infos[i], hi[i]
+            x.get("episode", {}).pop("t", None)
+            y.get("episode", {}).pop("t", None)
+            assert x.keys() == y.keys()
+            for key in x:
+                if isinstance(x[key], dict):
+                    assert x[key] == y[key], (key, k)
+                else:
+                    assert np.array_equal(np.asarray(x[key]), np.asarray(y[key]), equal_nan=True), (key, k)
+    with pytest.raises(RuntimeError):
+        a.fetch_host()
