@@ -63,6 +63,23 @@ def main(steps=1000, repeats=5):
     rate_sim(200)
     res["simulator6dof_rk4"] = float(np.median([rate_sim(steps) for _ in range(repeats)]))
     res["reference_python_steps_per_s"] = 730.0
+    # SB3's collect_rollouts loop (numpy actions in, numpy obs / rewards / dones out, infos of the finished envs read): calls per second
+    for n in (8, 256, 4096, 65536):
+        for mirror in (True, False):
+            env = BatchedRocket6DOF(n, cfg, numpy_io=True, host_mirror=mirror, remove_mass=True, clip_reward=(-1, 100), max_episode_steps=1500, seed=1)
+            env.reset()
+            act = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+
+            def loop(k):
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    obs, rew, dones, infos = env.step(act)
+                    for i in np.nonzero(dones)[0]:
+                        infos[int(i)].get("terminal_observation")
+                return k / (time.perf_counter() - t0)
+
+            loop(100)
+            res[f"numpy_io_{n}_{'mirror' if mirror else 'per_tensor'}_calls_per_s"] = float(np.median([loop(300) for _ in range(repeats)]))
     print(json.dumps(res))
 
 

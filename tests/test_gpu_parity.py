@@ -870,3 +870,18 @@ def test_host_mirror_changes_nothing(torch_cuda, cfg, n, kw):
                     assert np.array_equal(np.asarray(x[key]), np.asarray(y[key]), equal_nan=True), (key, k)
     with pytest.raises(RuntimeError):
         a.fetch_host()
+    # SB3's way of stepping (numpy in, numpy out) takes the mirror by itself: the same numbers as the per-tensor read-back
+    c = BatchedRocket6DOF(n, cfg, seed=5, numpy_io=True, **kw)
+    d = BatchedRocket6DOF(n, cfg, seed=5, numpy_io=True, host_mirror=False, **kw)
+    assert c._arena is not None and d._arena is None
+    assert np.array_equal(c.reset(), d.reset())
+    for k in range(40):
+        act = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        oc, od = c.step(act), d.step(act)
+        for x, y in zip(oc[:3], od[:3]):
+            assert isinstance(x, np.ndarray) and x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True), k
+        for i in np.nonzero(oc[2])[0][:4]:
+            x, y = oc[3][int(i)], od[3][int(i)]
+            x.get("episode", {}).pop("t", None)
+            y.get("episode", {}).pop("t", None)
+            assert x.keys() == y.keys() and all(np.array_equal(np.asarray(x[q]), np.asarray(y[q]), equal_nan=True) for q in x if not isinstance(x[q], dict))
