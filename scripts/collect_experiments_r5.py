@@ -156,6 +156,13 @@ E["compiler_scheduling_strategies_for_the_step_kernels (scripts/jobs/r5_job46.sh
     "rk4_raw_first_session (max-ilp, amdgpu-trackers, max-memory-clause)": pooled("r5_swap_sched.log"),
     "amdgpu_trackers": {"rk4_raw": pooled("r5_swap_trk_rk4.log"), "euler": pooled("r5_swap_trk_euler.log"), "fused_stack": pooled("r5_swap_trk_wrapped.log"),
                         "rk45": pooled("r5_swap_trk_rk45.log"), "rk4_2^23_envs": pooled("r5_swap_trk_2p23.log"), "step_k (base, trackers, base, trackers)": kbench("r5_kstep_trk.log")}}
+E["compiler_code_generation_switches_for_the_step_kernels (scripts/jobs/r5_job51.sh; library 0a21da9 sources; none kept)"] = {
+    "build": "scripts/build_variant.sh <name> -mllvm <switch>: prealloc = -amdgpu-prealloc-sgpr-spill-vgprs, nopostra = -enable-post-misched=0, relaxed = "
+             "-amdgpu-schedule-relaxed-occupancy, greedyrc = -greedy-regclass-priority-trumps-globalness, setprio = -amdgpu-set-wave-priority; "
+             "-amdgpu-max-memory-clause=32 and -amdgpu-schedule-metric-bias=100 give byte-identical step kernels (disassembly compared)",
+    "rk4_raw": pooled("r5_swap_cg_rk4.log"), "euler_dt_0.04": pooled("r5_swap_cg_euler.log"), "rk45": pooled("r5_swap_cg_rk45.log")}
+if js("r5_single_env_rate.json"):
+    E["host_driven_stepping_through_one_pinned_image (scripts/single_env_rate.py, scripts/jobs/r5_job50.sh)"] = js("r5_single_env_rate.json")
 _c4 = rd("r5_ppo_cfg4_mb.log")
 if "{" in _c4:
     E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])
