@@ -54,7 +54,9 @@ def _ds(f):
                   "steady_median_us": round(b["steady"]["median"], 2), "steady_p90_us": round(b["steady"]["p90"], 2), "timed_region_over_median": round(b["steady"]["timed_region_over_median"], 3)}
 E["driver_shape (review round 4, Next 1)"]["untraced_runs_with_the_round_5_bench (1 s pre-roll, steady record)"] = [x for x in (
     {"file": "profiles/r5_bench_line_driver_shape_slow_episode.json", "lib": "ce05765", "wall_us": 42.0, "hip_events_us": 41.0, "frac": 0.604, "steady_median_us": 36.97, "steady_p90_us": 39.99, "timed_region_over_median": 1.109},
-    _ds("r5_bench_driver_shape.json"), _ds("r5_bench_driver_shape_final.json")) if x]
+    {"file": "r5_bench_driver_shape_final.json (as first taken; the file was later overwritten by the run below)", "lib": "d6dc237", "wall_us": 37.17, "hip_events_us": 36.21, "frac": 0.684,
+     "steady_median_us": 36.88, "steady_p90_us": 41.12, "timed_region_over_median": 0.982},
+    _ds("r5_bench_driver_shape.json"), _ds("r5_bench_driver_shape_final.json"), _ds("r5_bench_driver_shape2.json")) if x]
 E["driver_shape (review round 4, Next 1)"]["untraced_runs_note"] = "three fresh boxes: two of the three 20-launch samples sat in a clock dip (1.09-1.11 x their own steady median), one did not (0.99)"
 tp = js("r5_timed_region_probe.json")
 if tp:
