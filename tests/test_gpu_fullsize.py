@@ -377,3 +377,45 @@ def test_reset_distribution_matches_the_reference_rule():
     # m0 / v0 of the fresh episodes (simulator.py:42-50, rocket_env.py:649-651)
     assert torch.equal(env.epconst[0, :n], env.state[13, :n])
     np.testing.assert_allclose(env.epconst[1, :n].cpu().numpy(), np.linalg.norm(st[:, 3:6], axis=1), rtol=2e-7)
+
+
+@pytest.mark.parametrize("integ,dt", [("rk4", 0.1), ("euler", 0.04)])
+def test_rows_beyond_4_gib_match_small_shards(torch_cuda, cfg, integ, dt):
+    """Maximum sizes: 2^27 + 77 envs on one GPU (128x the headline batch; 7.5 GB of SoA state whose rows start up to 7 GiB past the
+    base pointer, AoS observation / action blocks whose byte offsets pass 2^31 and 2^32) through the size-independent property the
+    domain offers: envs are independent and the reset RNG is keyed by the GLOBAL env index, so any window of the big batch equals,
+    bit for bit, a small env built with `env_offset` = the window's first env and stepped with the window's actions.  TimeLimit 6
+    puts every env through the in-kernel reset (queue entries, final_obs, episode sums at those offsets) within the run."""
+    torch = torch_cuda
+    from rl_rocket_6dof_amd import BatchedRocket6DOF
+
+    n, m, steps = (1 << 27) + 77, 4096, 14
+    kw = dict(seed=11, integrator=integ, timestep=dt, remove_mass=True, clip_reward=(-1, 100), max_episode_steps=6, record_flags=True)
+    big = BatchedRocket6DOF(n, cfg, **kw)
+    dev = big.device
+    # windows: the first tile, the envs whose observation rows straddle byte offsets 2^31 and 2^32, the ragged last tile
+    starts = [0, ((1 << 31) // 52 - m // 2) // 64 * 64, ((1 << 32) // 52 - m // 2) // 64 * 64, n - 77 - (m - 128)]
+    small = [BatchedRocket6DOF(min(m, n - s), cfg, env_offset=s, **kw) for s in starts]
+    big.reset()
+    for e in small:
+        e.reset()
+    g = torch.Generator(device=dev).manual_seed(9)
+    acts = [(torch.rand((n, 3), generator=g, device=dev) * 2 - 1) for _ in range(2)]
+    for k in range(steps):
+        a = acts[k & 1]
+        big.step_async(a)
+        for s, e in zip(starts, small):
+            e.step_async(a[s: s + e.num_envs].contiguous())
+        if k in (5, 6, steps - 1):          # the TimeLimit step, the step behind the resets, the last one
+            torch.cuda.synchronize()
+            for s, e in zip(starts, small):
+                w = e.num_envs
+                assert torch.equal(big.state[:, s: s + w], e.state[:, :w]), (k, s)
+                for name in ("obs", "reward", "done", "flags", "final_obs", "ep_step", "ep_return", "fin_return", "fin_length"):
+                    assert torch.equal(getattr(big, name)[s: s + w], getattr(e, name)), (name, k, s)
+            if k == 5:      # (nearly) every env truncated and re-sampled in this step; the few that ended earlier are mid-episode
+                assert int(big.done.sum().item()) > 0.999 * n
+    st = big.episode_stats()
+    assert 1.999 * n <= st["episodes"] <= 2.001 * n and st["truncated"] > 1.99 * n
+    del big, small, acts
+    torch.cuda.empty_cache()
