@@ -379,7 +379,7 @@ def test_reset_distribution_matches_the_reference_rule():
     np.testing.assert_allclose(env.epconst[1, :n].cpu().numpy(), np.linalg.norm(st[:, 3:6], axis=1), rtol=2e-7)
 
 
-@pytest.mark.parametrize("integ,dt", [("rk4", 0.1), ("euler", 0.04)])
+@pytest.mark.parametrize("integ,dt", [("rk4", 0.1), ("euler", 0.04), ("rk45", 0.1)])
 def test_rows_beyond_4_gib_match_small_shards(torch_cuda, cfg, integ, dt):
     """Maximum sizes: 2^27 + 77 envs on one GPU (128x the headline batch; 7.5 GB of SoA state whose rows start up to 7 GiB past the
     base pointer, AoS observation / action blocks whose byte offsets pass 2^31 and 2^32) through the size-independent property the
