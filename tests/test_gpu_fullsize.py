@@ -415,7 +415,19 @@ def test_rows_beyond_4_gib_match_small_shards(torch_cuda, cfg, integ, dt):
                     assert torch.equal(getattr(big, name)[s: s + w], getattr(e, name)), (name, k, s)
             if k == 5:      # (nearly) every env truncated and re-sampled in this step; the few that ended earlier are mid-episode
                 assert int(big.done.sum().item()) > 0.999 * n
+    # r6_step_k at this size: K = 3 steps in one launch (last step's outputs in the env's buffers), the windows again
+    ak = torch.stack([acts[0], acts[1], acts[0]])
+    big.step_k(ak, last_only=True)
+    for s, e in zip(starts, small):
+        e.step_k(ak[:, s: s + e.num_envs].contiguous(), last_only=True)
+    torch.cuda.synchronize()
+    for s, e in zip(starts, small):
+        w = e.num_envs
+        assert torch.equal(big.state[:, s: s + w], e.state[:, :w]), ("step_k", s)
+        for name in ("obs", "reward", "done", "flags", "ep_step", "ep_return"):
+            assert torch.equal(getattr(big, name)[s: s + w], getattr(e, name)), ("step_k", name, s)
     st = big.episode_stats()
     assert 1.999 * n <= st["episodes"] <= 2.001 * n and st["truncated"] > 1.99 * n
+    del ak
     del big, small, acts
     torch.cuda.empty_cache()
