@@ -542,11 +542,14 @@ def two_groups_side_measurement(torch, dev, cfg, rounds: int = 9, steps: int = 4
     return out
 
 
-def single_env_side_measurement(torch, dev, steps: int = 1000, repeats: int = 3) -> dict:
+def single_env_side_measurement(torch, dev, steps: int = 250, repeats: int = 2) -> dict:
     """BASELINE configs[0]: ONE env stepped from the host, 1000 random-action steps with a reset at every episode end -- the
     reference's own way of running (test_6DOF_environment.py:23-35, test_6DOF_simulator.py:3-7), through the single-env drop-ins
     `Rocket6DOF` / `Simulator6DOF` (rocket_env.py of this package: one lane of one wave does the work; a step is one launch,
-    two small copies through pinned images and one synchronisation).  Latency-bound by construction; a side figure."""
+    two small copies through pinned images and one synchronisation).  Latency-bound by construction; a side figure.  Kept short on
+    purpose (2 x 250 steps behind 100 per integrator; scripts/single_env_rate.py is the 5 x 1000-step form): the one-env RK4 launches
+    are launches of the headline's kernel instance, and a `rocprofv3 --stats` of this command averages over all of them -- 600 launches
+    of a few us next to the ~48 000 full-size ones move that average by 1 %."""
     import numpy as np
 
     from rl_rocket_6dof_amd import Rocket6DOF, Simulator6DOF, default_env_config
@@ -560,12 +563,12 @@ def single_env_side_measurement(torch, dev, steps: int = 1000, repeats: int = 3)
                 env.reset()
         return k / (time.perf_counter() - t0)
 
-    out = {"label": "BASELINE configs[0]: one env, host-driven, 1000 random-action steps, dt 0.1; env-steps/s (median of "
+    out = {"label": f"BASELINE configs[0]: one env, host-driven, {steps} random-action steps, dt 0.1; env-steps/s (median of "
                     f"{repeats}); the reference's Python on one Xeon core of the survey container: 730/s (BASELINE.md section 2)",
            "steps": steps, "reference_python_steps_per_s": 730.0}
     for integ in ("rk4", "rk45"):
         env = Rocket6DOF(**default_env_config(), device=dev, integrator=integ)
-        run(env, 200)
+        run(env, 100)
         out[f"rocket6dof_{integ}_steps_per_s"] = float(np.median([run(env, steps) for _ in range(repeats)]))
         env.close()
     ic = [100, 100, 100, 0, 3, 4, 1, 1, 0, 0, 0, 0, 0, 50e3]
@@ -579,7 +582,7 @@ def single_env_side_measurement(torch, dev, steps: int = 1000, repeats: int = 3)
         del sim.states[1:], sim.actions[1:], sim.times[1:]
         return k / (time.perf_counter() - t0)
 
-    run_sim(200)
+    run_sim(100)
     out["simulator6dof_rk4_steps_per_s"] = float(np.median([run_sim(steps) for _ in range(repeats)]))
     return out
 
