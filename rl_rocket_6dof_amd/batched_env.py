@@ -296,6 +296,7 @@ class BatchedRocket6DOF(VecEnv):
         self._arena = torch.zeros((off,), dtype=torch.uint8, device=self.device)
         self._host_arena = torch.zeros((off,), dtype=torch.uint8).pin_memory()
         self._host_action = torch.zeros((self.num_envs, ACTION_DIM), dtype=torch.float32).pin_memory()
+        self._host_action_np = self._host_action.numpy()
         self._act_event = torch.cuda.Event()
         for name, o, nbytes, dtype, shape in plan:
             setattr(self, name, self._arena[o:o + nbytes].view(dtype).view(shape))
@@ -392,7 +393,7 @@ class BatchedRocket6DOF(VecEnv):
             a = actions          # zero-copy
         elif self._arena is not None and not torch.is_tensor(actions):     # host actions through the pinned buffer: no staging copy
             self._act_event.synchronize()      # the previous upload has left the pinned buffer (a no-op when the caller synchronised)
-            self._host_action.numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, ACTION_DIM)
+            self._host_action_np[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, ACTION_DIM)
             self._act.copy_(self._host_action, non_blocking=True)
             self._act_event.record(torch.cuda.current_stream(self.device))
             a = self._act
