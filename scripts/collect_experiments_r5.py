@@ -165,6 +165,9 @@ E["compiler_code_generation_switches_for_the_step_kernels (scripts/jobs/r5_job51
     "rk4_raw": pooled("r5_swap_cg_rk4.log"), "euler_dt_0.04": pooled("r5_swap_cg_euler.log"), "rk45": pooled("r5_swap_cg_rk45.log")}
 if js("r5_single_env_rate.json"):
     E["host_driven_stepping_through_one_pinned_image (scripts/single_env_rate.py, scripts/jobs/r5_job50.sh)"] = js("r5_single_env_rate.json")
+if js("r5_single_env_rate_poll.json"):
+    E["host_driven_stepping_with_a_polling_runtime (HSA_ENABLE_INTERRUPT=0, scripts/jobs/r5_job53.sh; same box, interrupt | polling: no gain)"] = {
+        "interrupt": js("r5_single_env_rate_irq.json"), "polling": js("r5_single_env_rate_poll.json")}
 _c4 = rd("r5_ppo_cfg4_mb.log")
 if "{" in _c4:
     E["ppo_configs4_minibatch_size (scripts/jobs/r5_job36.sh)"] = json.loads(_c4[_c4.index("{"):])
