@@ -384,8 +384,9 @@ def build_line(args, world: int, n: int, dt: float, wall: float, kernel_ms: floa
 
 
 def timed_loop(env, pool, steps: int, k: int, barrier, stream, torch, every=None):
-    """Times `steps` env steps (launches of k steps each) between two barriers; returns (wall seconds, ms per env step
-    on the launch stream).  `every` = (period, fn): fn() is called after each `period` steps inside the timed region."""
+    """Times `steps` env steps (launches of k steps each) between two barriers (each = synchronize + process-group barrier +
+    synchronize); returns (this rank's wall seconds from behind the opening barrier to its own synchronize in front of the closing
+    one, ms per env step on the launch stream).  `every` = (period, fn): fn() is called after each `period` steps inside the timed region."""
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     npool = len(pool)
     barrier()
@@ -402,8 +403,14 @@ def timed_loop(env, pool, steps: int, k: int, barrier, stream, torch, every=None
             if every is not None and ((j + 1) * k) % every[0] == 0:
                 every[1]()
     ev1.record(stream)
-    barrier()
+    torch.cuda.synchronize()           # THIS rank's `steps` steps are done: its clock stops here ...
     wall = time.perf_counter() - t0
+    barrier()                          # ... and the closing barrier follows.  The job's time is the MAX over the ranks' clocks
+    #                                    (reduce_bench_times), as the contract prescribes; with the barrier inside the clock every rank
+    #                                    would read the same time plus the barrier's own latency -- a host-side gloo barrier of two
+    #                                    ranks cost 140 us in round 4's two-rank record (9.857 ms wall against 9.716 ms of kernels),
+    #                                    a fifth of the driver's 0.8 ms timed region, charged to nobody's env steps.  At N = 1 the
+    #                                    barrier is a second synchronize and nothing changes.
     return wall, ev0.elapsed_time(ev1) / steps
 
 
