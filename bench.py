@@ -931,6 +931,10 @@ def main(argv=None):
 
     stream = torch.cuda.current_stream(dev)
     if args.preroll_seconds > 0:
+        # the ranks start their pre-roll together: it runs by wall time, and a rank that got here 0.3 s early (its env was built
+        # sooner) would sit idle in the next barrier for as long -- 20 ms of idleness are enough for the chip to clock down, and that
+        # rank's timed region (the job's time is the slowest rank's) would then run at 39-45 us per step
+        barrier()
         preroll(env, pool, args.preroll_seconds, args.k, lambda: torch.cuda.synchronize(dev), args.preroll_batch)     # untimed, by time
     timed_loop(env, pool, max(args.warmup, args.k), args.k, barrier, stream, torch)        # W untimed steps
     wall, kernel_ms = timed_loop(env, pool, args.steps, args.k, barrier, stream, torch)    # EXACTLY K timed steps
