@@ -732,6 +732,22 @@ def rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev) 
 RANK_SCRIPT = os.path.abspath(__file__)
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr for the duration (native code that writes to stdout, e.g. gloo's connection banner)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _free_port() -> int:
     import socket
 
@@ -856,7 +872,8 @@ def main(argv=None):
 
     # R6_DIST_BACKEND=gloo + R6_FORCE_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
     # (RCCL refuses two ranks per device); the driver's real runs use the defaults (nccl, LOCAL_RANK).
-    rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
+    with _stdout_to_stderr():
+        rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
     # R6_FORCE_PROCESS_GROUP=1: a process group of ONE rank (backend nccl = RCCL by default) and the N > 1 code path on it --
     # every collective of that path (device barrier, all-gathers of times and episode summaries) then really goes through
     # RCCL on the one GPU a builder has; the numbers are those of a 1-GPU run
@@ -905,7 +922,8 @@ def main(argv=None):
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: do not depend on the hostname resolving
         try:
-            host_group = dist.new_group(backend="gloo")
+            with _stdout_to_stderr():      # gloo announces "[Gloo] Rank r is connected to ..." on the C++ side's stdout: this job's
+                host_group = dist.new_group(backend="gloo")     # stdout carries the ONE JSON line and nothing else
         except Exception as e:
             print(f"[bench] rank {rank}: gloo group unavailable ({e})", file=sys.stderr)
             host_group = None
