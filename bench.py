@@ -872,8 +872,10 @@ def main(argv=None):
 
     # R6_DIST_BACKEND=gloo + R6_FORCE_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
     # (RCCL refuses two ranks per device); the driver's real runs use the defaults (nccl, LOCAL_RANK).
-    with _stdout_to_stderr():
-        rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
+    # From here to the JSON line, file descriptor 1 points at stderr: native code announces itself on stdout (gloo's "[Gloo] Rank r is
+    # connected ...", RCCL's five-line version banner at its first collective), and this job's stdout carries the ONE line and nothing else
+    quiet = _stdout_to_stderr().__enter__()
+    rank, world, local = r6dist.init_from_env(backend=os.environ.get("R6_DIST_BACKEND"))
     # R6_FORCE_PROCESS_GROUP=1: a process group of ONE rank (backend nccl = RCCL by default) and the N > 1 code path on it --
     # every collective of that path (device barrier, all-gathers of times and episode summaries) then really goes through
     # RCCL on the one GPU a builder has; the numbers are those of a 1-GPU run
@@ -922,8 +924,7 @@ def main(argv=None):
         if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: do not depend on the hostname resolving
         try:
-            with _stdout_to_stderr():      # gloo announces "[Gloo] Rank r is connected to ..." on the C++ side's stdout: this job's
-                host_group = dist.new_group(backend="gloo")     # stdout carries the ONE JSON line and nothing else
+            host_group = dist.new_group(backend="gloo")
         except Exception as e:
             print(f"[bench] rank {rank}: gloo group unavailable ({e})", file=sys.stderr)
             host_group = None
@@ -969,32 +970,41 @@ def main(argv=None):
                       "ms_per_step adds the start-up of the first launch after the barrier and the host's wake-up (~1.7 us per step at 20 steps)")
         extras["steady"] = st
     if multi:
-        rccl_live[0] = True
-        red = r6dist.reduce_bench_times(wall, kernel_ms, device=dev)
+        # the job's time = the slowest rank's (host floats: over the gloo group when there is one, so that the record of the timed
+        # region does not depend on the device collectives coming up afterwards)
+        red = r6dist.reduce_bench_times(wall, kernel_ms, device=dev, group=host_group)
         wall, kernel_ms = red["wall_max"], red["kernel_ms_max"]
-        # the one collective of the design (episode summaries, SURVEY 8e) inside a second, short timed loop:
-        # BASELINE configs[4]'s per-rollout exchange.  Its own env, with the episode accounting the summaries come from
-        # (ep_step / ep_return rows, +16 B per env-step and the statistics): the headline loop above stays the raw step at
-        # every N, so that the driver's scaling ratios compare like with like
-        env_g = env if wrapped else BatchedRocket6DOF(
-            n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=rank * n, auto_reset=True,
-            record_flags=False, record_terms=False, track_episodes=True, seed=42)
-        if env_g is not env:
-            env_g.reset()
-            if args.k <= 1:
-                for j in range(args.burnin):
-                    env_g.step_async(pool[j % args.pool])
-            else:
-                for j in range(max(1, args.burnin // args.k)):
-                    env_g.step_k(pool[j % args.pool], last_only=True)
-                env_g._bench_out = env_g.step_k(pool[0])
-        gather = rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev)
-        gather["value"] = n * world * gather["steps"] / gather.pop("wall_s")
         extras["rccl"] = {"backend": backend, "rccl_ranks": dist.get_world_size(), "devices": red["devices"],
                           "kernel_us_min": red["kernel_ms_min"] * 1e3, "kernel_us_max": red["kernel_ms_max"] * 1e3,
                           "wall_s_min": red["wall_min"], "wall_s_max": red["wall_max"],
-                          "verified_with_more_than_one_rank": dist.get_world_size() > 1,
-                          "with_rollout_gather": gather}
+                          "verified_with_more_than_one_rank": dist.get_world_size() > 1}
+        # the one collective of the design (episode summaries, SURVEY 8e) inside a second, short timed loop:
+        # BASELINE configs[4]'s per-rollout exchange.  Its own env, with the episode accounting the summaries come from
+        # (ep_step / ep_return rows, +16 B per env-step and the statistics): the headline loop above stays the raw step at
+        # every N, so that the driver's scaling ratios compare like with like.  From here on the barriers go through the
+        # device backend too (RCCL's communicator comes up at its first collective).  An error of the device collectives that
+        # every rank sees (RCCL not coming up on this node) is recorded in the line instead of costing the job its record.
+        try:
+            rccl_live[0] = True
+            env_g = env if wrapped else BatchedRocket6DOF(
+                n, cfg, device=dev, integrator=args.integrator, timestep=args.dt, env_offset=rank * n, auto_reset=True,
+                record_flags=False, record_terms=False, track_episodes=True, seed=42)
+            if env_g is not env:
+                env_g.reset()
+                if args.k <= 1:
+                    for j in range(args.burnin):
+                        env_g.step_async(pool[j % args.pool])
+                else:
+                    for j in range(max(1, args.burnin // args.k)):
+                        env_g.step_k(pool[j % args.pool], last_only=True)
+                    env_g._bench_out = env_g.step_k(pool[0])
+            gather = rollout_gather_loop(env_g, pool, args, barrier, stream, torch, r6dist, dev)
+            gather["value"] = n * world * gather["steps"] / gather.pop("wall_s")
+            extras["rccl"]["with_rollout_gather"] = gather
+        except Exception as e:      # noqa: BLE001 -- whatever the backend raises
+            print(f"[bench] rank {rank}: rollout-gather loop failed: {type(e).__name__}: {e}", file=sys.stderr)
+            extras["rccl"]["with_rollout_gather"] = {"error": f"{type(e).__name__}: {e}"[:600]}
+            rccl_live[0] = host_group is None      # the closing barrier over gloo when there is a gloo group
 
     if rank == 0:
         dt = args.dt or cfg["timestep"]
@@ -1027,11 +1037,17 @@ def main(argv=None):
         if not multi and not args.no_cpu_baseline and args.cpu_seconds > 0:
             extras["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         line = build_line(args, world, n, dt, wall, kernel_ms, traffic=traffic, traffic_source=source, extras=extras)
+        quiet.__exit__()
         print(json.dumps(line), flush=True)
+        quiet.__enter__()         # the teardown below may talk as well
 
     if multi:
-        barrier()
-        dist.destroy_process_group()
+        try:
+            barrier()
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001 -- the line is out; a teardown error must not turn the job's exit code
+            print(f"[bench] rank {rank}: teardown: {type(e).__name__}: {e}", file=sys.stderr)
+    quiet.__exit__()
 
 
 if __name__ == "__main__":

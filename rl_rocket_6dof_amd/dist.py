@@ -112,17 +112,19 @@ def gather_episode_stats_device(vec: torch.Tensor) -> torch.Tensor:
     return torch.stack(rows).to(vec.device)
 
 
-def reduce_bench_times(wall_s: float, kernel_ms: float, device=None) -> Dict[str, object]:
+def reduce_bench_times(wall_s: float, kernel_ms: float, device=None, group=None) -> Dict[str, object]:
     """Min / max over ranks of a rank's wall time and per-step kernel time (bench.py: the job's time is the slowest
-    rank's), plus the device index every rank ran on.  One all-gather of three float64 per rank: through the device for
-    RCCL (backend nccl), on the host for gloo; the identity without a process group."""
+    rank's), plus the device index every rank ran on.  One all-gather of three float64 per rank: on the host through
+    ``group`` when one is given (a gloo group: the numbers are host floats, and the job's record then does not depend on the
+    device collectives coming up), else through the device for RCCL (backend nccl), on the host for gloo; the identity
+    without a process group."""
     dev_index = torch.cuda.current_device() if torch.cuda.is_available() else -1
     vec = torch.tensor([wall_s, kernel_ms, float(dev_index)], dtype=torch.float64)
     if _collectives_on():
-        if dist.get_backend() == "nccl":
+        if group is None and dist.get_backend() == "nccl":
             vec = vec.to(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         rows = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
-        dist.all_gather(rows, vec)
+        dist.all_gather(rows, vec, group=group)
         table = torch.stack(rows).cpu()
     else:
         table = vec.reshape(1, 3)
