@@ -183,6 +183,10 @@ def _worker(rank, world, port, q):
     # what main() does after its timed loops, with the GPU part replaced by fixed per-rank numbers
     wall, kernel_ms = (0.080, 0.0380) if rank == 0 else (0.084, 0.0402)
     red = r6dist.reduce_bench_times(wall, kernel_ms)
+    # the same reduction through an explicit host group (what bench.py does when the default backend is RCCL: the record of the
+    # timed region must not wait for the device collectives) gives the same numbers
+    host_group = dist.new_group(backend="gloo")
+    assert r6dist.reduce_bench_times(wall, kernel_ms, group=host_group) == red
     # the gloo-or-RCCL decision of bench.py is a GROUP decision: one rank without a gloo group switches every rank
     assert r6dist.all_ranks_agree(True, "t1") is True
     assert r6dist.all_ranks_agree(rank != 1, "t2") is False
